@@ -1,0 +1,413 @@
+#!/usr/bin/env python3
+"""Generate golden vectors G1..G9 from the REFERENCE's own Python functions.
+
+Runs only in the build container (needs /root/reference mounted read-only):
+
+    python tests/golden/gen_golden.py
+
+It imports sitrack/{util,locate,tracking}.py through tests/golden/refload.py,
+calls the reference functions on seeded inputs and commits ONLY the numeric
+inputs/outputs as small .npz files next to this script.  The hot loop itself
+(si3_part_tracker.py:361-496) lives under `__main__` and cannot be imported, so
+`reference_loop()` below drives the imported reference predicates in that
+loop's order.  cartopy/netCDF4 are absent, so the
+projection fixture G7 is read from the reference's committed NetCDF data file
+with the image's `h5dump`.
+"""
+import contextlib
+import io
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+from refload import load_reference  # noqa: E402
+from sitrack_amd import synthetic as syn  # noqa: E402
+
+util, locate, tracking = load_reference()
+FILL = -9999.0
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()):
+        yield
+
+
+def save(name, **kw):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **kw)
+    print("%-28s %8.1f KB" % (name, os.path.getsize(path) / 1024.))
+
+
+# --------------------------------------------------------------------------- G1
+def g1_inside():
+    rng = np.random.default_rng(1234)
+    quads, pts = [], []
+    # the reference's own manual test (tools/tests/test_pnt_inside_quad.py:16-24)
+    q0 = np.array([[0., 0.], [3., 0.], [4., 4.], [1., 3.5]])
+    for p in ([2., 2.], [6., 6.], [-1., 2.], [3.1, 3.6]):
+        quads.append(q0); pts.append(p)
+    # random convex-ish and arbitrary quads, points in the bounding box
+    for _ in range(1500):
+        c = rng.uniform(-50, 50, 2)
+        ang = np.sort(rng.uniform(0, 2 * np.pi, 4))
+        rad = rng.uniform(1, 6, 4)
+        q = np.stack([c[0] + rad * np.sin(ang), c[1] + rad * np.cos(ang)], axis=1)
+        if rng.random() < 0.3:
+            q = q[rng.permutation(4)]             # self-intersecting / clockwise
+        quads.append(q); pts.append(c + rng.uniform(-7, 7, 2))
+    # axis-aligned cells: points on edges, vertices, horizontal edges (stale xints)
+    for _ in range(600):
+        y0, x0 = rng.integers(-5, 5, 2) * 4.0
+        q = np.array([[y0, x0], [y0, x0 + 4], [y0 + 4, x0 + 4], [y0 + 4, x0]])
+        if rng.random() < 0.3:
+            q = np.roll(q, rng.integers(0, 4), axis=0)
+        ch = rng.integers(0, 6)
+        yy = [y0, y0 + 4, y0 + 2, y0 + rng.uniform(0, 4), y0 - 1, y0 + 5][ch]
+        ch = rng.integers(0, 6)
+        xx = [x0, x0 + 4, x0 + 2, x0 + rng.uniform(0, 4), x0 - 1, x0 + 5][ch]
+        quads.append(q); pts.append([yy, xx])
+    # trapezoids with one horizontal edge and a point level with it
+    for _ in range(300):
+        y0 = rng.uniform(-5, 5); x0 = rng.uniform(-5, 5)
+        q = np.array([[y0, x0], [y0, x0 + 3], [y0 + rng.uniform(1, 3), x0 + 3.5], [y0 + rng.uniform(1, 3), x0 - 0.5]])
+        k = rng.integers(0, 4)
+        p = [q[k, 0], q[k, 1] + rng.choice([-1., 0., 1.])]
+        quads.append(q); pts.append(p)
+    quads = np.array(quads); pts = np.array(pts, dtype=np.float64)
+    out = np.array([locate.IsInsideQuadrangle(p[0], p[1], q) for p, q in zip(pts, quads)], dtype=bool)
+    assert list(out[:4]) == [True, False, False, True]
+    save("g1_inside.npz", quads=quads, pts=pts, inside=out)
+
+
+# --------------------------------------------------------------------------- G2
+def g2_intersect():
+    rng = np.random.default_rng(1235)
+    n = 3000
+    P = rng.uniform(-10, 10, (n, 4, 2))
+    # integer lattice cases -> exact collinear / touching configurations
+    m = 1200
+    L = rng.integers(-3, 4, (m, 4, 2)).astype(np.float64)
+    P = np.concatenate([P, L])
+    out = np.array([tracking.intersect2Seg(list(p[0]), list(p[1]), list(p[2]), list(p[3])) for p in P], dtype=bool)
+    ccw = np.array([tracking._ccw_(list(p[0]), list(p[1]), list(p[2])) for p in P], dtype=bool)
+    save("g2_intersect.npz", P=P, intersect=out, ccw=ccw)
+
+
+# --------------------------------------------------------------------------- G3
+def g3_crossing():
+    rng = np.random.default_rng(1236)
+    g = syn.make_grid(40, 44, dkm=4.0, warp=1.0)
+    Yf, Xf = g["Yf"], g["Xf"]
+    n = 2500
+    jiT = np.stack([rng.integers(3, 37, n), rng.integers(3, 41, n)], axis=1).astype(np.int64)
+    P1 = np.empty((n, 2)); P2 = np.empty((n, 2))
+    icross = np.empty(n, dtype=np.int64); inhc = np.empty(n, dtype=np.int64)
+    vert_in = np.empty((n, 2, 4), dtype=np.int64)
+    vert_out = np.empty((n, 2, 4), dtype=np.int64)
+    jiT_out = np.empty((n, 2), dtype=np.int64)
+    for k in range(n):
+        j, i = jiT[k]
+        vert = np.array([[j - 1, j - 1, j, j], [i - 1, i, i, i - 1]], dtype=np.int64)
+        quad = np.array([[Yf[vert[0, c], vert[1, c]], Xf[vert[0, c], vert[1, c]]] for c in range(4)])
+        w = rng.dirichlet(np.ones(4))
+        p1 = w @ quad                                     # inside the cell
+        mode = k % 5
+        if mode == 0:      # short move, may or may not leave: fall-through cases included
+            p2 = p1 + rng.normal(0, 1.5, 2)
+        elif mode == 1:    # towards a vertex -> diagonal moves
+            c = rng.integers(0, 4)
+            p2 = p1 + (quad[c] - p1) * rng.uniform(1.02, 1.6)
+        elif mode == 2:    # long move
+            p2 = p1 + rng.normal(0, 5.0, 2)
+        elif mode == 3:    # P1 outside the cell, P2 further (no edge intersected -> 4)
+            p1 = quad.mean(axis=0) + np.array([9., 9.])
+            p2 = p1 + rng.normal(0, 1.0, 2)
+        else:              # exactly through a vertex
+            c = rng.integers(0, 4)
+            p2 = p1 + (quad[c] - p1) * 2.0
+        P1[k], P2[k] = p1, p2
+        vert_in[k] = vert
+        ic = tracking.CrossedEdge(list(p1), list(p2), vert, Yf, Xf)
+        nh = tracking.NewHostCell(ic, list(p1), list(p2), vert, Yf, Xf)
+        v2, t2 = tracking.UpdtInd4NewCell(nh, vert.copy(), jiT[k].copy())
+        icross[k], inhc[k] = ic, nh
+        vert_out[k], jiT_out[k] = v2, t2
+    assert set(np.unique(inhc)) == set(range(1, 9)), np.unique(inhc)
+    save("g3_crossing.npz", Yf=Yf, Xf=Xf, jiT=jiT, vert=vert_in, P1=P1, P2=P2,
+         icross=icross, inhc=inhc, vert_out=vert_out, jiT_out=jiT_out)
+
+
+# --------------------------------------------------------------------------- G4
+def g4_survive():
+    rng = np.random.default_rng(1237)
+    Nj, Ni = 24, 30
+    tmask = (rng.random((Nj, Ni)) > 0.12).astype(np.int8)
+    sic = rng.choice([0.0, 0.05, 0.09, 0.1, 0.11, 0.3, 1.0], size=(Nj, Ni)).astype(np.float64)
+    sic32 = rng.uniform(0, 0.3, (Nj, Ni)).astype(np.float32)     # fp32 field promoted like the driver does
+    jj, ii = np.meshgrid(np.arange(Nj), np.arange(Ni), indexing="ij")
+    jiT = np.stack([jj.ravel(), ii.ravel()], axis=1).astype(np.int64)
+    with quiet():
+        k1 = np.array([tracking.Survive(0, list(t), tmask, pIceC=sic) for t in jiT], dtype=np.int64)
+        k2 = np.array([tracking.Survive(0, list(t), tmask, pIceC=sic32.astype(np.float64)) for t in jiT], dtype=np.int64)
+        ones = np.ones((Nj, Ni), dtype=np.int8)
+        k3 = np.array([tracking.Survive(0, list(t), ones, pIceC=sic32.astype(np.float64)) for t in jiT], dtype=np.int64)
+    save("g4_survive.npz", tmask=tmask, sic=sic, sic32=sic32, jiT=jiT, kill_a=k1, kill_b=k2, kill_c=k3)
+
+
+# --------------------------------------------------------------------------- G5
+def polar_grid(Nj, Ni, dkm, warp, yc=-300., xc=200.):
+    """Synthetic grid placed near the pole; lat/lon of T-points from the build's own
+    inverse projection (inputs only -- any consistent lat/lon would do)."""
+    from oracle import oracle as orc
+    g = syn.make_grid(Nj, Ni, dkm=dkm, warp=warp)
+    for k in ("Yt", "Yu", "Yv", "Yf"):
+        g[k] = g[k] + yc
+    for k in ("Xt", "Xu", "Xv", "Xf"):
+        g[k] = g[k] + xc
+    ll = orc.CartNPSkm2Geo1D(np.stack([g["Yt"].ravel(), g["Xt"].ravel()], axis=1))
+    g["latT"] = np.ascontiguousarray(ll[:, 0].reshape(Nj, Ni))
+    g["lonT"] = np.ascontiguousarray(np.mod(ll[:, 1], 360.).reshape(Nj, Ni))   # ncio.py:50
+    return g
+
+
+def g5_seedinit():
+    from oracle import oracle as orc
+    rng = np.random.default_rng(1238)
+    Nj, Ni, dkm = 40, 44, 12.0
+    g = polar_grid(Nj, Ni, dkm, warp=1.0)
+    tmask = g["tmask"].copy()
+    tmask[18:22, 10:14] = 0
+    sic = np.ones((Nj, Ni)); sic[5:12, 30:40] = 0.02; sic[25:30, 5:9] = 0.12
+    # seeds: random inside, exactly on T-points, near F-points (slightly off the tie), off-grid
+    yx = []
+    n_rand = 260
+    ylo, yhi = g["Yt"].min(), g["Yt"].max(); xlo, xhi = g["Xt"].min(), g["Xt"].max()
+    for _ in range(n_rand):
+        yx.append([rng.uniform(ylo - 30, yhi + 30), rng.uniform(xlo - 30, xhi + 30)])
+    for _ in range(60):
+        j, i = rng.integers(0, Nj), rng.integers(0, Ni)
+        yx.append([g["Yt"][j, i], g["Xt"][j, i]])
+    for _ in range(60):
+        j, i = rng.integers(2, Nj - 2), rng.integers(2, Ni - 2)
+        yx.append([g["Yf"][j, i] + rng.normal(0, 0.3), g["Xf"][j, i] + rng.normal(0, 0.3)])
+    for _ in range(40):   # ring just around the acceptance radius 0.5*1.2^7*resol of an edge point
+        i = rng.integers(3, Ni - 3)
+        r = rng.uniform(1.5, 2.1) * g["resol"][0, 0]
+        yx.append([g["Yt"][0, i] - r, g["Xt"][0, i]])
+    yx = np.array(yx)
+    nP = yx.shape[0]
+    ll = orc.CartNPSkm2Geo1D(yx)
+    # seeds reach SeedInit as float32 promoted to float64 with lon mod 360 (ncio.py:294-309)
+    pSG = np.stack([ll[:, 0].astype(np.float32).astype(np.float64),
+                    np.mod(ll[:, 1].astype(np.float32).astype(np.float64), 360.)], axis=1)
+    pSC = yx.astype(np.float32).astype(np.float64)
+    ids = (np.arange(nP) + 1).astype(np.int64) * 7
+    # NearestPoint alone (whole-domain form, as called from tracking.py:134)
+    npj = np.empty((nP, 2), dtype=np.int64)
+    dmin = np.empty(nP)
+    with quiet():
+        for k in range(nP):
+            jy, jx = locate.NearestPoint((pSG[k, 0], pSG[k, 1]), g["latT"], g["lonT"], rd_found_km=tracking.rFoundKM,
+                                         resolkm=g["resol"], max_itr=10)
+            npj[k] = (jy, jx)
+            xd = util.Haversine(pSG[k, 0], pSG[k, 1], g["latT"], g["lonT"])
+            dmin[k] = xd.min()
+        # plain-radius variants (no 2-D resolution)
+        np_plain = np.array([locate.NearestPoint((pSG[k, 0], pSG[k, 1]), g["latT"], g["lonT"], rd_found_km=8.,
+                                                 max_itr=5) for k in range(0, nP, 7)], dtype=np.int64)
+        # FindContainingCell from the found nearest point
+        fcc_ok = np.zeros(nP, dtype=bool); fcc_ji = np.zeros((nP, 2), dtype=np.int64); fcc_v = np.zeros((nP, 2, 4), dtype=np.int64)
+        for k in range(nP):
+            if npj[k, 0] >= 2 and npj[k, 0] < Nj - 2 and npj[k, 1] >= 2 and npj[k, 1] < Ni - 2:
+                ok, ji, vv = locate.FindContainingCell((pSC[k, 0], pSC[k, 1]), (npj[k, 0], npj[k, 1]), g["Yf"], g["Xf"])
+                fcc_ok[k] = ok; fcc_ji[k] = ji; fcc_v[k] = np.array(vv)
+        out = tracking.SeedInit(ids.copy(), pSG.copy(), pSC.copy(), g["latT"], g["lonT"], g["Yf"], g["Xf"],
+                                g["resol"], tmask, xIceConc=sic, iverbose=0)
+    nPn, oSG, oSC, oIDs, ojiT, overt, okeep = out
+    print("   G5: %d seeds -> %d kept; nearest-not-found %d" % (nP, nPn, (npj[:, 0] < 0).sum()))
+    save("g5_seedinit.npz", latT=g["latT"], lonT=g["lonT"], Yf=g["Yf"], Xf=g["Xf"], resol=g["resol"],
+         tmask=tmask, sic=sic, ids=ids, pSG=pSG, pSC=pSC, nearest=npj, dmin=dmin, nearest_plain=np_plain,
+         fcc_ok=fcc_ok, fcc_ji=fcc_ji, fcc_vert=fcc_v,
+         nPn=np.int64(nPn), oSG=oSG, oSC=oSC, oIDs=oIDs, ojiT=np.asarray(ojiT), overt=np.asarray(overt), okeep=okeep)
+
+
+# --------------------------------------------------------------------------- G6
+def reference_loop(g, tmask, u, v, sic, yx0, jiT0, vert0, rec_first, rec_last, kstrt, Nt, rdt, strategy):
+    """Drives the reference predicates in the order of si3_part_tracker.py:361-496.
+
+    Field record jrec uses slab jrec % K.  Returns per-record positions (FillValue
+    where a buoy did not step), masks, and the final index/alive state.
+    """
+    Yf, Xf, Yu, Xu, Yv, Xv = (g[k] for k in ("Yf", "Xf", "Yu", "Xu", "Yv", "Xv"))
+    K = u.shape[0]
+    nP = yx0.shape[0]
+    alive = np.ones(nP, dtype="i1")
+    msk = np.zeros((Nt + 1, nP), dtype="i1")
+    pos = np.zeros((Nt + 1, nP, 2)) + FILL
+    jit_rec = np.zeros((Nt + 1, nP, 2), dtype=np.int64)
+    alive_rec = np.zeros((Nt + 1, nP), dtype="i1")
+    mesh = np.zeros((nP, 4, 2))
+    still = np.zeros(nP, dtype=bool)
+    jiT = jiT0.copy(); vert = vert0.copy()
+    for b in range(nP):
+        k0 = rec_first[b] - kstrt
+        pos[k0, b, :] = yx0[b]
+        msk[k0, b] = 1
+    jit_rec[0] = jiT; alive_rec[0] = alive
+    codes = np.zeros(9, dtype=np.int64)
+    xIC = np.zeros_like(Yf); xU = np.zeros_like(Yf); xV = np.zeros_like(Yf)
+    for jt in range(Nt):
+        jrec = jt + kstrt
+        xIC[:, :] = sic[jrec % K]; xU[:, :] = u[jrec % K]; xV[:, :] = v[jrec % K]
+        for b in range(nP):
+            if alive[b] == 1 and jrec >= rec_first[b] and jrec <= rec_last[b]:
+                ry, rx = pos[jt, b, :]
+                if not still[b]:
+                    vj, vi = vert[b]
+                    mesh[b] = [[Yf[vj[c], vi[c]], Xf[vj[c], vi[c]]] for c in range(4)]
+                jT, iT = jiT[b]
+                if strategy == 0:
+                    zU = 0.5 * (xU[jT, iT] + xU[jT, iT - 1])
+                    zV = 0.5 * (xV[jT, iT] + xV[jT - 1, iT])
+                else:
+                    F = [Yf[jT, iT], Xf[jT, iT]]
+                    um1 = tracking.intersect2Seg([ry, rx], F, [Yv[jT - 1, iT], Xv[jT - 1, iT]], [Yv[jT, iT], Xv[jT, iT]])
+                    vm1 = tracking.intersect2Seg([ry, rx], F, [Yu[jT, iT - 1], Xu[jT, iT - 1]], [Yu[jT, iT], Xu[jT, iT]])
+                    zU = xU[jT, iT - 1] if um1 else xU[jT, iT]
+                    zV = xV[jT - 1, iT] if vm1 else xV[jT, iT]
+                dx = zU * rdt
+                dy = zV * rdt
+                rxn = rx + dx / 1000.
+                ryn = ry + dy / 1000.
+                pos[jt + 1, b, :] = [ryn, rxn]
+                msk[jt + 1, b] = 1
+                lin = locate.IsInsideQuadrangle(ryn, rxn, mesh[b])
+                still[b] = lin
+                if not lin:
+                    ic = tracking.CrossedEdge([ry, rx], [ryn, rxn], vert[b], Yf, Xf)
+                    nh = tracking.NewHostCell(ic, [ry, rx], [ryn, rxn], vert[b], Yf, Xf)
+                    codes[nh] += 1
+                    vert[b], jiT[b] = tracking.UpdtInd4NewCell(nh, vert[b], jiT[b])
+                    if tracking.Survive(0, jiT[b], tmask, pIceC=xIC) > 0:
+                        alive[b] = 0
+        jit_rec[jt + 1] = jiT; alive_rec[jt + 1] = alive
+    return pos, msk, jit_rec, alive_rec, vert, codes
+
+
+def g6_trajectories():
+    rng = np.random.default_rng(1239)
+    Nj, Ni, dkm = 48, 48, 4.0
+    nP, Nt, K, kstrt, rdt = 128, 64, 8, 3, 3600.
+    for tag, warp in (("curvi", 1.0), ("regular", 0.0)):
+        g = syn.make_grid(Nj, Ni, dkm=dkm, warp=warp)
+        u, v, sic = syn.make_fields(g, K=K, seed=2024, umax=0.75, drift=0.25, ripple=0.12)
+        tmask = g["tmask"].copy()
+        tmask[30:34, 28:33] = 0                    # island
+        sic = sic.copy()
+        for k in range(K):
+            sic[k, 8:14, 6 + k:14 + k] = 0.04      # drifting open-water patch
+        _, cand = syn.make_buoys(g, 2 * nP, seed=1234, frac=0.72)
+        if warp == 0.0:
+            # put some buoys exactly on cell edges / vertices of the regular grid
+            cand[:8, 0] = g["Yf"][20:28, 0]
+            cand[4:12, 1] = g["Xf"][0, 18:26]
+        # host cells with the reference's own FindContainingCell, from the nearest T-point in the plane
+        yx0 = np.zeros((nP, 2)); jiT0 = np.zeros((nP, 2), dtype=np.int64); vert0 = np.zeros((nP, 2, 4), dtype=np.int64)
+        b = 0
+        for c in cand:
+            d2 = (g["Yt"] - c[0]) ** 2 + (g["Xt"] - c[1]) ** 2
+            gj, gi = np.unravel_index(np.argmin(d2), d2.shape)
+            ok, ji, vv = locate.FindContainingCell((c[0], c[1]), (gj, gi), g["Yf"], g["Xf"])
+            if ok and b < nP:
+                yx0[b] = c; jiT0[b] = ji; vert0[b] = np.array(vv); b += 1
+        assert b == nP, (tag, b)
+        ids = np.arange(1, nP + 1, dtype=np.int64) * 3 + 300534062025510   # IDs reach 3e14 (tools/sidfexloc.dat:1)
+        rec_first = np.full(nP, kstrt, dtype=np.int64)
+        rec_last = np.full(nP, kstrt + Nt - 1, dtype=np.int64)
+        late = rng.choice(nP, 12, replace=False)
+        rec_first[late] = kstrt + rng.integers(1, 20, 12)
+        early = rng.choice(nP, 12, replace=False)
+        rec_last[early] = kstrt + Nt - 1 - rng.integers(1, 20, 12)
+        out = {}
+        for strat in (1, 0):
+            with quiet():
+                pos, msk, jit_rec, alive_rec, vert, codes = reference_loop(
+                    g, tmask, u.astype(np.float64), v.astype(np.float64), sic.astype(np.float64),
+                    yx0, jiT0, vert0, rec_first, rec_last, kstrt, Nt, rdt, strat)
+            print("   G6 %-8s strat %d: crossings by code %s  dead %d/%d" %
+                  (tag, strat, codes[1:].tolist(), int((alive_rec[-1] == 0).sum()), nP))
+            out["pos_s%d" % strat] = pos
+            out["msk_s%d" % strat] = msk
+            out["jiT_s%d" % strat] = jit_rec.astype(np.int32)
+            out["alive_s%d" % strat] = alive_rec
+            out["vert_s%d" % strat] = vert
+            out["codes_s%d" % strat] = codes
+        save("g6_traj_%s.npz" % tag, warp=np.float64(warp), dkm=np.float64(dkm), Nj=np.int64(Nj), Ni=np.int64(Ni),
+             tmask=tmask, u=u, v=v, sic=sic, ids=ids, yx0=yx0, jiT0=jiT0, vert0=vert0,
+             rec_first=rec_first, rec_last=rec_last, kstrt=np.int64(kstrt), Nt=np.int64(Nt), rdt=np.float64(rdt), **out)
+
+
+# --------------------------------------------------------------------------- G7
+def h5_values(path, name, fmt):
+    txt = subprocess.run(["/opt/conda/bin/h5dump", "-m", fmt, "-d", name, path], check=True,
+                         capture_output=True, text=True).stdout
+    body = txt.split("DATA {", 1)[1].split("}", 1)[0]
+    body = re.sub(r"\(\d+(,\d+)*\):", " ", body)
+    return [t for t in re.split(r"[,\s]+", body) if t]
+
+
+def g7_projection():
+    f = "/root/reference/tools/nc/sitrack_seeding_sidfex_19961215_00_HSS5.nc__KEEP"
+    lat = np.array(h5_values(f, "latitude", "%.9g"), dtype=np.float32)
+    lon = np.array(h5_values(f, "longitude", "%.9g"), dtype=np.float32)
+    ypos = np.array(h5_values(f, "y_pos", "%.9g"), dtype=np.float32)
+    xpos = np.array(h5_values(f, "x_pos", "%.9g"), dtype=np.float32)
+    ids = np.array(h5_values(f, "id_buoy", "%ld"), dtype=np.int64)
+    tim = np.array(h5_values(f, "time", "%d"), dtype=np.int64)
+    # the text file the seeding tool read (tools/sidfexloc.dat: id lon lat)
+    dat = np.genfromtxt("/root/reference/tools/sidfexloc.dat")
+    print("   G7 ids", ids.tolist())
+    save("g7_projection.npz", id_buoy=ids, time=tim, latitude=lat, longitude=lon, y_pos=ypos, x_pos=xpos,
+         dat_lonlat=dat[:, 1:3], dat_id=dat[:, 0].astype(np.int64))
+
+
+# --------------------------------------------------------------------------- G8
+def g8_timespan():
+    cases = []
+    base = 850608000           # 1996-12-15 00:00 UTC (the fixture's time)
+    vt = base + 1800 + 3600 * np.arange(48)
+    for sd, stop in ((base, None), (base + 3600, None), (base + 5 * 3600 + 1800, None), (base, base + 10 * 3600),
+                     (base + 7200, base + 30 * 3600 + 1799), (base + 1800, vt[-1]), (base + 3 * 3600, base + 3 * 3600 + 1800)):
+        with quiet():
+            r = tracking.GetTimeSpan(3600., vt, sd, vt[0], vt[-1], iStop=stop)
+        cases.append([sd, -1 if stop is None else stop] + [int(x) for x in r])
+    save("g8_timespan.npz", vtime=vt.astype(np.int64), cases=np.array(cases, dtype=np.int64))
+
+
+# --------------------------------------------------------------------------- G9
+def g9_haversine():
+    rng = np.random.default_rng(1240)
+    n = 4000
+    plat = rng.uniform(55, 90, n); plon = rng.uniform(0, 360, n)
+    xlat = np.clip(plat + rng.normal(0, 2, n), -90, 90); xlon = np.mod(plon + rng.normal(0, 5, n), 360.)
+    xlat[:50] = plat[:50]; xlon[:50] = plon[:50]
+    d = np.array([util.Haversine(plat[k], plon[k], xlat[k:k + 1], xlon[k:k + 1])[0] for k in range(n)])
+    save("g9_haversine.npz", plat=plat, plon=plon, xlat=xlat, xlon=xlon, dist=d)
+
+
+if __name__ == "__main__":
+    only = sys.argv[1:]
+    for name, fn in (("g1", g1_inside), ("g2", g2_intersect), ("g3", g3_crossing), ("g4", g4_survive),
+                     ("g5", g5_seedinit), ("g6", g6_trajectories), ("g7", g7_projection), ("g8", g8_timespan),
+                     ("g9", g9_haversine)):
+        if not only or name in only:
+            fn()

@@ -1,0 +1,176 @@
+"""Pins the CPU oracle (oracle/sitrk_oracle.c) against golden vectors produced by
+the reference's own Python functions (tests/golden/gen_golden.py) and against the
+reference's own known answers.  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from sitrack_amd import synthetic as syn
+
+
+def test_g1_is_inside_quadrangle(golden):
+    g = golden("g1_inside.npz")
+    got = np.array([orc.IsInsideQuadrangle(p[0], p[1], q) for p, q in zip(g["pts"], g["quads"])])
+    # reference's own manual test, tools/tests/test_pnt_inside_quad.py:16-24
+    assert list(got[:4]) == [True, False, False, True]
+    assert np.array_equal(got, g["inside"])
+
+
+def test_g2_intersect2seg_and_ccw(golden):
+    g = golden("g2_intersect.npz")
+    P = g["P"]
+    got = np.array([orc.intersect2Seg(p[0], p[1], p[2], p[3]) for p in P])
+    ccw = np.array([orc.ccw(p[0], p[1], p[2]) for p in P])
+    assert np.array_equal(got, g["intersect"])
+    assert np.array_equal(ccw, g["ccw"])
+
+
+def test_g3_crossing_chain(golden):
+    g = golden("g3_crossing.npz")
+    Yf, Xf = g["Yf"], g["Xf"]
+    for k in range(len(g["jiT"])):
+        ic = orc.CrossedEdge(g["P1"][k], g["P2"][k], g["vert"][k], Yf, Xf)
+        nh = orc.NewHostCell(ic, g["P1"][k], g["P2"][k], g["vert"][k], Yf, Xf)
+        v2, t2 = orc.UpdtInd4NewCell(nh, g["vert"][k], g["jiT"][k])
+        assert ic == g["icross"][k] and nh == g["inhc"][k], k
+        assert np.array_equal(v2, g["vert_out"][k]) and np.array_equal(t2, g["jiT_out"][k])
+        # VRTCS stays a pure function of vJIt
+        assert np.array_equal(orc.vertices_of(t2[None, :])[0], v2)
+    assert set(np.unique(g["inhc"])) == set(range(1, 9))
+
+
+def test_updt_unknown_direction_is_an_error():
+    with pytest.raises(IndexError):
+        orc.UpdtInd4NewCell(9, np.zeros((2, 4), dtype=np.int64), np.zeros(2, dtype=np.int64))
+
+
+def test_g4_survive(golden):
+    g = golden("g4_survive.npz")
+    ones = np.ones_like(g["tmask"])
+    a = np.array([orc.Survive(t, g["tmask"], g["sic"]) for t in g["jiT"]])
+    b = np.array([orc.Survive(t, g["tmask"], g["sic32"].astype(np.float64)) for t in g["jiT"]])
+    c = np.array([orc.Survive(t, ones, g["sic32"].astype(np.float64)) for t in g["jiT"]])
+    assert np.array_equal(a, g["kill_a"])
+    assert np.array_equal(b, g["kill_b"])
+    assert np.array_equal(c, g["kill_c"])
+
+
+def test_survive_uses_asymmetric_stencil():
+    # tracking.py:79: the 5th point is [j-1,i-1], not [j-1,i]
+    tm = np.ones((9, 9), dtype=np.int8)
+    sic = np.ones((9, 9))
+    tm[3, 4] = 0          # [j-1,i] of (4,4): must NOT kill
+    assert orc.Survive((4, 4), tm, sic) == 0
+    tm[3, 4] = 1
+    tm[3, 3] = 0          # [j-1,i-1]: kills
+    assert orc.Survive((4, 4), tm, sic, return_which=True) == (1, 2)
+
+
+def test_g9_haversine(golden):
+    g = golden("g9_haversine.npz")
+    d = np.array([orc.Haversine(g["plat"][k], g["plon"][k], g["xlat"][k:k + 1], g["xlon"][k:k + 1])[0]
+                  for k in range(len(g["plat"]))])
+    # numpy's vector sin/cos/arcsin and libm may differ in the last bits
+    assert np.allclose(d, g["dist"], rtol=1e-12, atol=1e-9)
+    assert np.all(d[:50] == 0.0)
+
+
+def test_g5_nearest_point_and_cells(golden):
+    g = golden("g5_seedinit.npz")
+    nP = len(g["ids"])
+    for k in range(nP):
+        jy, jx, dmin = orc.NearestPoint(g["pSG"][k], g["latT"], g["lonT"], rd_found_km=orc.rFoundKM,
+                                        resolkm=g["resol"], max_itr=10, return_dist=True)
+        assert (jy, jx) == tuple(g["nearest"][k]), k
+        assert abs(dmin - g["dmin"][k]) <= 1e-9 + 1e-12 * g["dmin"][k]
+    plain = np.array([orc.NearestPoint(g["pSG"][k], g["latT"], g["lonT"], rd_found_km=8., max_itr=5)
+                      for k in range(0, nP, 7)])
+    assert np.array_equal(plain, g["nearest_plain"])
+    Nj, Ni = g["latT"].shape
+    for k in range(nP):
+        jy, jx = g["nearest"][k]
+        if 2 <= jy < Nj - 2 and 2 <= jx < Ni - 2:
+            ok, ji, vv = orc.FindContainingCell(g["pSC"][k], (jy, jx), g["Yf"], g["Xf"])
+            assert ok == bool(g["fcc_ok"][k]), k
+            assert np.array_equal(ji, g["fcc_ji"][k]) and np.array_equal(vv, g["fcc_vert"][k]), k
+
+
+def test_nearest_point_acceptance_threshold(golden):
+    # with max_itr=10 the loop reduces to  d_min < 0.5*1.2**7*resol
+    g = golden("g5_seedinit.npz")
+    fac = 0.5 * 1.2 ** 7
+    for k in range(len(g["ids"])):
+        jy, jx, dmin = orc.NearestPoint(g["pSG"][k], g["latT"], g["lonT"], rd_found_km=orc.rFoundKM,
+                                        resolkm=g["resol"], max_itr=10, return_dist=True)
+        if abs(dmin / g["resol"][0, 0] - fac) > 1e-6:
+            assert (jy >= 0) == (dmin < fac * g["resol"][0, 0])
+
+
+def test_g5_seedinit(golden):
+    g = golden("g5_seedinit.npz")
+    nPn, oSG, oSC, oIDs, ojiT, overt, okeep = orc.SeedInit(g["ids"], g["pSG"], g["pSC"], g["latT"], g["lonT"],
+                                                           g["Yf"], g["Xf"], g["resol"], g["tmask"], g["sic"])
+    assert nPn == int(g["nPn"])
+    assert np.array_equal(okeep, g["okeep"])
+    assert np.array_equal(oIDs, g["oIDs"])
+    assert np.array_equal(ojiT, g["ojiT"])
+    assert np.array_equal(overt, g["overt"])
+    assert np.array_equal(oSG, g["oSG"]) and np.array_equal(oSC, g["oSC"])
+
+
+@pytest.mark.parametrize("tag", ["curvi", "regular"])
+@pytest.mark.parametrize("strat", [1, 0])
+def test_g6_trajectories_bit_exact(golden, tag, strat):
+    g = golden("g6_traj_%s.npz" % tag)
+    grid = syn.make_grid(int(g["Nj"]), int(g["Ni"]), dkm=float(g["dkm"]), warp=float(g["warp"]))
+    grid["tmask"] = g["tmask"]
+    tr = orc.Tracker(grid, g["yx0"], g["jiT0"], vert0=g["vert0"], rec_first=g["rec_first"], rec_last=g["rec_last"],
+                     rdt=float(g["rdt"]), uv_strategy=strat)
+    K, kstrt, Nt = g["u"].shape[0], int(g["kstrt"]), int(g["Nt"])
+    pos, msk, jit, alive = g["pos_s%d" % strat], g["msk_s%d" % strat], g["jiT_s%d" % strat], g["alive_s%d" % strat]
+    for jt in range(Nt):
+        jrec = jt + kstrt
+        pn, mn = tr.step(jrec, g["u"][jrec % K], g["v"][jrec % K], g["sic"][jrec % K])
+        # a buoy whose window opens at jt+1 has its seed position pre-written in the reference array
+        opening = (g["rec_first"] - kstrt) == (jt + 1)
+        assert np.array_equal(pn[~opening], pos[jt + 1][~opening]), (jt, "positions must be bit-exact")
+        assert np.array_equal(mn[~opening], msk[jt + 1][~opening])
+        assert np.array_equal(tr.jiT, jit[jt + 1])
+        assert np.array_equal(tr.alive, alive[jt + 1])
+    assert np.array_equal(tr.vert, g["vert_s%d" % strat])
+    assert tr.ncross == int(g["codes_s%d" % strat].sum())
+
+
+def test_g7_forward_projection_matches_reference_fixture(golden):
+    # tools/nc/sitrack_seeding_sidfex_19961215_00_HSS5.nc__KEEP: (lat,lon) f4 -> (y_pos,x_pos) f4 made by the
+    # reference's cartopy forward projection from tools/sidfexloc.dat
+    g = golden("g7_projection.npz")
+    assert np.array_equal(g["id_buoy"], g["dat_id"])
+    ll = np.stack([g["dat_lonlat"][:, 1], g["dat_lonlat"][:, 0]], axis=1)
+    assert np.array_equal(ll[:, 0].astype(np.float32), g["latitude"])
+    assert np.array_equal(ll[:, 1].astype(np.float32), g["longitude"])
+    yx = orc.Geo2CartNPSkm1D(ll)
+    assert np.array_equal(yx[:, 0].astype(np.float32), g["y_pos"])
+    assert np.array_equal(yx[:, 1].astype(np.float32), g["x_pos"])
+
+
+def test_g7_inverse_projection_round_trip(golden):
+    g = golden("g7_projection.npz")
+    ll = np.stack([g["dat_lonlat"][:, 1], g["dat_lonlat"][:, 0]], axis=1)
+    back = orc.CartNPSkm2Geo1D(orc.Geo2CartNPSkm1D(ll))
+    assert np.allclose(back, ll, rtol=0, atol=1e-8)
+    rng = np.random.default_rng(7)
+    ll = np.stack([rng.uniform(40, 89.999, 5000), rng.uniform(-180, 180, 5000)], axis=1)
+    back = orc.CartNPSkm2Geo1D(orc.Geo2CartNPSkm1D(ll))
+    assert np.allclose(back, ll, rtol=0, atol=1e-8)
+    # dead buoys hold -9999 km (si3_part_tracker.py:327,493): still a finite lat/lon
+    dead = orc.CartNPSkm2Geo1D(np.array([[-9999., -9999.]]))
+    assert np.all(np.isfinite(dead)) and -180 <= dead[0, 1] <= 180
+
+
+def test_g8_get_time_span(golden):
+    g = golden("g8_timespan.npz")
+    vt = g["vtime"]
+    for c in g["cases"]:
+        sd, stop = int(c[0]), (None if c[1] < 0 else int(c[1]))
+        assert orc.GetTimeSpan(3600., vt, sd, vt[0], vt[-1], iStop=stop) == tuple(int(x) for x in c[2:])
