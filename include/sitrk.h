@@ -1,0 +1,163 @@
+/*
+ * sitrk.h -- C ABI of libsitrk.so: MI355X (gfx950) per-buoy advection for the
+ * `sitrack` Lagrangian sea-ice tracker.
+ *
+ * The reference (stephanieleroux/sitrack) is pure Python and has no FFI of its
+ * own; the boundary this library replaces is the body of the record loop of
+ * si3_part_tracker.py:361-496 and the `sit.*` calls made from it.  Each entry
+ * point below cites the reference code it stands for.  Plain pointers and
+ * sizes only; host arrays are C-contiguous, order [j,i] / [y,x] / [lat,lon]
+ * like the reference.  A maintainer binds it from Python with ctypes (see
+ * INTEGRATION.md); sitrack_amd/_lib.py is that binding.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative SITRK_E* code; the
+ *     text is available from sitrk_last_error().  The library never prints
+ *     and never exits (the reference's `print(...); exit(0)` convention,
+ *     e.g. sitrack/tracking.py:18-20,301-303, becomes an error return).
+ *   - one context = one GPU = one host thread at a time (not re-entrant per
+ *     handle, no global state).  Multi-GPU = one process per GPU, each with
+ *     its own context and its own contiguous range of buoys.
+ *   - the caller owns all host buffers; no host pointer is retained after a
+ *     call returns.  Device pointers passed to *_dev entry points must stay
+ *     valid until the next sitrk_sync()/fetch.
+ *   - there is NO CPU fallback: without a usable HIP device sitrk_create()
+ *     fails with SITRK_EHIP.
+ */
+#ifndef SITRK_H
+#define SITRK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SITRK_VERSION 100          /* 0.1.0 */
+
+#define SITRK_OK        0
+#define SITRK_EINVAL  (-1)         /* bad argument / call order                        */
+#define SITRK_EINDEX  (-2)         /* index the reference would fault on (IndexError)  */
+#define SITRK_EHIP    (-3)         /* HIP runtime error (text in sitrk_last_error)     */
+#define SITRK_ENOMEM  (-4)
+
+#define SITRK_F32 0                /* field record element types */
+#define SITRK_F64 1
+
+#define SITRK_FILL (-9999.0)       /* sitrack/ncio.py:19 FillValue */
+
+typedef struct sitrk_ctx sitrk_t;
+
+/* ---- context ----------------------------------------------------------- */
+int         sitrk_version(void);
+int         sitrk_create(sitrk_t **h, int device);
+int         sitrk_destroy(sitrk_t *h);
+const char *sitrk_last_error(sitrk_t *h);           /* h may be NULL: last create() error */
+int         sitrk_sync(sitrk_t *h);                 /* wait for all queued work          */
+/* adopt an external compute stream (hipStream_t as void*), e.g. the caller's
+ * torch stream; NULL restores the library's own stream */
+int         sitrk_set_stream(sitrk_t *h, void *hip_stream);
+
+/* ---- static model grid -------------------------------------------------
+ * The arrays GetModelGrid / GetModelUVGrid hand to the loop
+ * (sitrack/ncio.py:22-92; si3_part_tracker.py:192,196): F-, U-, V-point plane
+ * coordinates [km] and the T-point land-sea mask.  Copied to the device once and
+ * re-laid out as one 48-byte record per cell.  4 <= Nj <= 32767, 4 <= Ni <= 65535. */
+int sitrk_set_grid(sitrk_t *h, int Nj, int Ni,
+                   const double *Yf, const double *Xf,
+                   const double *Yu, const double *Xu,
+                   const double *Yv, const double *Xv,
+                   const int8_t *tmask);
+
+/* module-level constants of the reference, same defaults:
+ * rdt = 3600 (si3_part_tracker.py:31), iUVstrategy = 1 (:37),
+ * rmin_conc = 0.1 (sitrack/tracking.py:4) */
+int sitrk_set_params(sitrk_t *h, double rdt, int uv_strategy, double rmin_conc);
+
+/* ---- model records (u_ice, v_ice, siconc) -------------------------------
+ * si3_part_tracker.py:372-374 reads one (Nj,Ni) slab of each per record.
+ * `nslots` records are resident on the device; a slot is one contiguous slab
+ * [u | v | siconc] of 3*Nj*Ni elements of `dtype` (what one RCCL broadcast moves). */
+int   sitrk_alloc_records(sitrk_t *h, int nslots, int dtype);
+int   sitrk_push_record(sitrk_t *h, int slot, const void *u, const void *v, const void *sic);   /* host pointers   */
+int   sitrk_push_record_dev(sitrk_t *h, int slot, const void *slab_dev);                        /* device pointer: [u|v|sic] */
+void *sitrk_record_ptr(sitrk_t *h, int slot);   /* device address of a slot's slab (broadcast target); NULL on error */
+
+/* ---- buoys ---------------------------------------------------------------
+ * State of si3_part_tracker.py:324-330 reduced to what the loop reads:
+ * yx = xPosC[jt] (nP,2) km; jiT = vJIt (nP,2); rec_first/rec_last =
+ * z1stModelRec/zLstModelRec (:264-265), NULL = every record.  VRTCS is a pure
+ * function of vJIt (sitrack/locate.py:320-321, tracking.py:257-300) and is not
+ * stored.  All buoys start alive.  Requires 1 <= jT <= Nj-2, 1 <= iT <= Ni-2
+ * (outside it the reference indexes out of range) -> SITRK_EINDEX. */
+int sitrk_set_buoys(sitrk_t *h, int64_t nP, const double *yx, const int32_t *jiT,
+                    const int32_t *rec_first, const int32_t *rec_last);
+
+/* re-order the device-resident buoys by host cell (coalescing); results are
+ * always returned in the caller's original order.  resort_every > 0 re-sorts
+ * automatically every that many steps. */
+int sitrk_sort_buoys(sitrk_t *h);
+int sitrk_set_resort(sitrk_t *h, int resort_every);
+
+/* One model record for every buoy: the body of `for jP in range(nP)`
+ * (si3_part_tracker.py:378-490): gate (:380), velocity pick (:423-441,
+ * sitrack/tracking.py:44-58), Euler update (:452-458), IsInsideQuadrangle
+ * (:466, locate.py:49-78), CrossedEdge / NewHostCell / UpdtInd4NewCell / Survive
+ * (:474-484, tracking.py:62-93,182-305).  `slot` = resident record used as
+ * model record `jrec`.  Asynchronous. */
+int sitrk_step(sitrk_t *h, int slot, int jrec);
+
+/* nsteps records jrec0, jrec0+1, ... using slots (slot0 + k) % nslots */
+int sitrk_run(sitrk_t *h, int slot0, int jrec0, int nsteps);
+
+/* Current state in the caller's buoy order (any pointer may be NULL):
+ * yx (nP,2) current position; jiT (nP,2) = vJIt; alive (nP) = iAlive;
+ * kill_rec (nP) = model record at which the buoy was killed, -1 if alive. */
+int sitrk_fetch(sitrk_t *h, double *yx, int32_t *jiT, int8_t *alive, int32_t *kill_rec);
+
+/* What the reference stores for the record that followed model record `jrec`
+ * (xPosC[jt+1], xmask[jt+1], si3_part_tracker.py:459-460): the position where
+ * the buoy stepped at `jrec`, FillValue and mask 0 elsewhere.  Valid right
+ * after the step of `jrec`.  latlon (optional) = CartNPSkm2Geo1D of yx_rec
+ * (:493; dead buoys' -9999 km are converted too, like the reference). */
+int sitrk_fetch_record(sitrk_t *h, int jrec, double *yx_rec, int8_t *mask, double *latlon);
+
+/* ---- locate / seeding ----------------------------------------------------
+ * FindContainingCell (sitrack/locate.py:280-330) for n points: from the guess
+ * T-point tries centre, i+1, j+1, i-1, j-1.  found[k] 1/0; jiT_out = centre of
+ * the found cell (last candidate tried when not found).  Needs set_grid. */
+int sitrk_find_cells(sitrk_t *h, int64_t n, const double *yx, const int32_t *jiT_guess,
+                     int32_t *jiT_out, int8_t *found);
+
+/* SeedInit (sitrack/tracking.py:98-178), per-seed part: nearest T-point by
+ * Haversine (locate.py:222-276, util.py:85-103) with the acceptance test of
+ * NearestPoint as called there (rd_found_km = rFoundKM = 2.5, max_itr = 10, 2-D
+ * resolkm), Survive on that T-point, FindContainingCell.  Outputs are NOT
+ * compacted: keep[k] in {0,1}, why[k] (optional) 0 kept / 1 no nearest point /
+ * 2 Survive / 3 no containing cell; the caller compacts with where(keep==1)
+ * exactly like tracking.py:166-178.  sic: (Nj,Ni) fp64 ice concentration at
+ * the seeding record (si3_part_tracker.py:228-229). */
+int sitrk_seed_init(sitrk_t *h, int64_t nP, const double *latlon, const double *yx,
+                    const double *latT, const double *lonT, const double *resolkm,
+                    const double *sic, int32_t *jiT_out, int8_t *keep, int8_t *why);
+
+/* ---- projection -----------------------------------------------------------
+ * CartNPSkm2Geo1D / Geo2CartNPSkm1D (sitrack/util.py:394-429): WGS84 polar
+ * stereographic, lat_ts = lat0, lon_0 = lon0 (defaults 70, -45 in the
+ * reference), km <-> degrees, arrays (n,2) [y,x] <-> [lat,lon]. */
+int sitrk_cart2geo(sitrk_t *h, int64_t n, const double *yx, double lat0, double lon0, double *latlon);
+int sitrk_geo2cart(sitrk_t *h, int64_t n, const double *latlon, double lat0, double lon0, double *yx);
+
+/* ---- measurement ----------------------------------------------------------
+ * HIP events on the library's compute stream (torch.cuda.Event would only see
+ * torch's stream).  timer_stop waits for the stop event and returns the elapsed ms. */
+int sitrk_timer_start(sitrk_t *h);
+int sitrk_timer_stop(sitrk_t *h, float *ms);
+/* iAlive.sum() -- the per-record "current number of buoys alive" line of the
+ * reference driver (si3_part_tracker.py:376) */
+int sitrk_count_alive(sitrk_t *h, int64_t *nalive);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SITRK_H */

@@ -1,0 +1,9 @@
+"""sitrack_amd -- MI355X-native per-buoy advection for the `sitrack` sea-ice tracker.
+
+Import as `import sitrack_amd as sit`: the hot-path functions keep the reference's
+names (`sit.SeedInit`, `sit.CartNPSkm2Geo1D`, `sit.GetTimeSpan`, ...).
+"""
+from ._lib import Context, SitrkError, FillValue, build, lib, SO_PATH      # noqa: F401
+from .tracking import (SeedInit, FindContainingCell, CartNPSkm2Geo1D, Geo2CartNPSkm1D, GetTimeSpan,  # noqa: F401
+                       IceTracker, vertices_of, default_context, rmin_conc, rFoundKM)
+from . import synthetic                                                      # noqa: F401

@@ -1,0 +1,296 @@
+"""ctypes binding of libsitrk.so (include/sitrk.h).
+
+The extension is built in-tree (sitrack_amd/csrc/Makefile -> sitrack_amd/libsitrk.so)
+and loaded from there.  There is no CPU fallback: if the library is missing, or no
+HIP device is usable, the product raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libsitrk.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+SITRK_F32, SITRK_F64 = 0, 1
+FillValue = -9999.0
+
+_vp = C.c_void_p
+_i64 = C.c_int64
+_int = C.c_int
+_dbl = C.c_double
+
+# every symbol include/sitrk.h declares: (restype, argtypes)
+_SIGNATURES = {
+    "sitrk_version": (_int, []),
+    "sitrk_create": (_int, [C.POINTER(_vp), _int]),
+    "sitrk_destroy": (_int, [_vp]),
+    "sitrk_last_error": (C.c_char_p, [_vp]),
+    "sitrk_sync": (_int, [_vp]),
+    "sitrk_set_stream": (_int, [_vp, _vp]),
+    "sitrk_set_grid": (_int, [_vp, _int, _int] + [_vp] * 7),
+    "sitrk_set_params": (_int, [_vp, _dbl, _int, _dbl]),
+    "sitrk_alloc_records": (_int, [_vp, _int, _int]),
+    "sitrk_push_record": (_int, [_vp, _int, _vp, _vp, _vp]),
+    "sitrk_push_record_dev": (_int, [_vp, _int, _vp]),
+    "sitrk_record_ptr": (_vp, [_vp, _int]),
+    "sitrk_set_buoys": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "sitrk_sort_buoys": (_int, [_vp]),
+    "sitrk_set_resort": (_int, [_vp, _int]),
+    "sitrk_step": (_int, [_vp, _int, _int]),
+    "sitrk_run": (_int, [_vp, _int, _int, _int]),
+    "sitrk_fetch": (_int, [_vp, _vp, _vp, _vp, _vp]),
+    "sitrk_fetch_record": (_int, [_vp, _int, _vp, _vp, _vp]),
+    "sitrk_count_alive": (_int, [_vp, C.POINTER(_i64)]),
+    "sitrk_find_cells": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "sitrk_seed_init": (_int, [_vp, _i64] + [_vp] * 9),
+    "sitrk_cart2geo": (_int, [_vp, _i64, _vp, _dbl, _dbl, _vp]),
+    "sitrk_geo2cart": (_int, [_vp, _i64, _vp, _dbl, _dbl, _vp]),
+    "sitrk_timer_start": (_int, [_vp]),
+    "sitrk_timer_stop": (_int, [_vp, C.POINTER(C.c_float)]),
+}
+
+
+class SitrkError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """Compile libsitrk.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC] + (["-B"] if force else [])
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or r.returncode:
+        print(r.stdout + r.stderr)
+    if r.returncode:
+        raise SitrkError("building libsitrk.so failed (hipcc --offload-arch=gfx950)")
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the in-tree extension; raise loudly if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise SitrkError("%s not found: build it with `make -C %s` (or __graft_entry__.build()); "
+                             "sitrack_amd has no CPU fallback" % (SO_PATH, CSRC))
+        L = C.CDLL(SO_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def as_c(a, dtype, shape=None, name="array"):
+    """C-contiguous array of `dtype` (copy only when needed); validates the shape."""
+    b = np.ascontiguousarray(a, dtype=dtype)
+    if shape is not None and tuple(b.shape) != tuple(shape):
+        raise ValueError("%s: expected shape %s, got %s" % (name, tuple(shape), tuple(b.shape)))
+    return b
+
+
+class Context:
+    """Owns one sitrk_t handle (= one GPU)."""
+
+    def __init__(self, device=0):
+        self._L = lib()
+        h = _vp()
+        rc = self._L.sitrk_create(C.byref(h), int(device))
+        if rc:
+            raise SitrkError("sitrk_create: %s" % self._L.sitrk_last_error(None).decode())
+        self._h = h
+        self.device = int(device)
+        self.Nj = self.Ni = 0
+        self.nP = 0
+        self.nslots = 0
+        self.field_dtype = None
+
+    # -- plumbing
+    def _chk(self, rc):
+        if rc:
+            msg = self._L.sitrk_last_error(self._h).decode()
+            if rc == -2:
+                raise IndexError(msg)
+            raise SitrkError(msg)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.sitrk_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def sync(self):
+        self._chk(self._L.sitrk_sync(self._h))
+
+    def set_stream(self, hip_stream):
+        self._chk(self._L.sitrk_set_stream(self._h, hip_stream))
+
+    # -- grid / params / records
+    def set_grid(self, Yf, Xf, Yu, Xu, Yv, Xv, tmask):
+        Yf = as_c(Yf, np.float64)
+        Nj, Ni = Yf.shape
+        arrs = [Yf] + [as_c(a, np.float64, (Nj, Ni), n) for a, n in
+                       ((Xf, "Xf"), (Yu, "Yu"), (Xu, "Xu"), (Yv, "Yv"), (Xv, "Xv"))]
+        tm = as_c(tmask, np.int8, (Nj, Ni), "tmask")
+        self._chk(self._L.sitrk_set_grid(self._h, Nj, Ni, *[_ptr(a) for a in arrs], _ptr(tm)))
+        self.Nj, self.Ni = Nj, Ni
+        self.nP = 0
+        self.nslots = 0
+
+    def set_params(self, rdt=3600., uv_strategy=1, rmin_conc=0.1):
+        self._chk(self._L.sitrk_set_params(self._h, float(rdt), int(uv_strategy), float(rmin_conc)))
+
+    def alloc_records(self, nslots, dtype=np.float32):
+        dt = np.dtype(dtype)
+        if dt not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise ValueError("records must be float32 or float64")
+        self._chk(self._L.sitrk_alloc_records(self._h, int(nslots), SITRK_F64 if dt == np.float64 else SITRK_F32))
+        self.nslots = int(nslots)
+        self.field_dtype = dt
+
+    def push_record(self, slot, u, v, sic):
+        shp = (self.Nj, self.Ni)
+        u = as_c(u, self.field_dtype, shp, "u")
+        v = as_c(v, self.field_dtype, shp, "v")
+        sic = as_c(sic, self.field_dtype, shp, "sic")
+        self._chk(self._L.sitrk_push_record(self._h, int(slot), _ptr(u), _ptr(v), _ptr(sic)))
+        self.sync()             # u,v,sic may be temporaries
+
+    def push_record_dev(self, slot, dev_ptr):
+        self._chk(self._L.sitrk_push_record_dev(self._h, int(slot), _vp(dev_ptr)))
+
+    def record_ptr(self, slot):
+        p = self._L.sitrk_record_ptr(self._h, int(slot))
+        if not p:
+            raise SitrkError("sitrk_record_ptr: bad slot %d" % slot)
+        return p
+
+    @property
+    def slab_elems(self):
+        return 3 * self.Nj * self.Ni
+
+    # -- buoys
+    def set_buoys(self, yx, jiT, rec_first=None, rec_last=None, sort=True):
+        yx = as_c(yx, np.float64)
+        nP = yx.shape[0]
+        yx = as_c(yx, np.float64, (nP, 2), "yx")
+        ji = np.asarray(jiT)
+        if ji.shape != (nP, 2):
+            raise ValueError("jiT: expected shape %s, got %s" % ((nP, 2), ji.shape))
+        ji32 = as_c(ji, np.int32)
+        if not np.array_equal(ji32, ji):
+            raise IndexError("jiT does not fit int32")
+        f = None if rec_first is None else as_c(rec_first, np.int32, (nP,), "rec_first")
+        l = None if rec_last is None else as_c(rec_last, np.int32, (nP,), "rec_last")
+        self._chk(self._L.sitrk_set_buoys(self._h, nP, _ptr(yx), _ptr(ji32), _ptr(f), _ptr(l)))
+        self.nP = nP
+        if sort:
+            self.sort_buoys()
+
+    def sort_buoys(self):
+        self._chk(self._L.sitrk_sort_buoys(self._h))
+
+    def set_resort(self, every):
+        self._chk(self._L.sitrk_set_resort(self._h, int(every)))
+
+    def step(self, slot, jrec):
+        self._chk(self._L.sitrk_step(self._h, int(slot), int(jrec)))
+
+    def run(self, slot0, jrec0, nsteps):
+        self._chk(self._L.sitrk_run(self._h, int(slot0), int(jrec0), int(nsteps)))
+
+    def fetch(self, want=("yx", "jiT", "alive", "kill_rec")):
+        nP = self.nP
+        out = {}
+        if "yx" in want:
+            out["yx"] = np.empty((nP, 2), dtype=np.float64)
+        if "jiT" in want:
+            out["jiT"] = np.empty((nP, 2), dtype=np.int32)
+        if "alive" in want:
+            out["alive"] = np.empty(nP, dtype=np.int8)
+        if "kill_rec" in want:
+            out["kill_rec"] = np.empty(nP, dtype=np.int32)
+        self._chk(self._L.sitrk_fetch(self._h, _ptr(out.get("yx")), _ptr(out.get("jiT")), _ptr(out.get("alive")),
+                                      _ptr(out.get("kill_rec"))))
+        return out
+
+    def fetch_record(self, jrec, latlon=False):
+        nP = self.nP
+        yx = np.empty((nP, 2), dtype=np.float64)
+        mask = np.empty(nP, dtype=np.int8)
+        ll = np.empty((nP, 2), dtype=np.float64) if latlon else None
+        self._chk(self._L.sitrk_fetch_record(self._h, int(jrec), _ptr(yx), _ptr(mask), _ptr(ll)))
+        return (yx, mask, ll) if latlon else (yx, mask)
+
+    def count_alive(self):
+        n = _i64(0)
+        self._chk(self._L.sitrk_count_alive(self._h, C.byref(n)))
+        return n.value
+
+    # -- locate / projection
+    def find_cells(self, yx, jiT_guess):
+        yx = as_c(yx, np.float64)
+        n = yx.shape[0]
+        g = as_c(jiT_guess, np.int32, (n, 2), "jiT_guess")
+        out = np.empty((n, 2), dtype=np.int32)
+        found = np.empty(n, dtype=np.int8)
+        self._chk(self._L.sitrk_find_cells(self._h, n, _ptr(yx), _ptr(g), _ptr(out), _ptr(found)))
+        return found.astype(bool), out
+
+    def seed_init(self, latlon, yx, latT, lonT, resolkm, sic):
+        latlon = as_c(latlon, np.float64)
+        nP = latlon.shape[0]
+        yx = as_c(yx, np.float64, (nP, 2), "pSC")
+        shp = (self.Nj, self.Ni)
+        latT = as_c(latT, np.float64, shp, "latT")
+        lonT = as_c(lonT, np.float64, shp, "lonT")
+        res = None if resolkm is None else as_c(resolkm, np.float64, shp, "resolkm")
+        sic = as_c(sic, np.float64, shp, "sic")
+        jiT = np.zeros((nP, 2), dtype=np.int32)
+        keep = np.zeros(nP, dtype=np.int8)
+        why = np.zeros(nP, dtype=np.int8)
+        self._chk(self._L.sitrk_seed_init(self._h, nP, _ptr(latlon), _ptr(yx), _ptr(latT), _ptr(lonT), _ptr(res), _ptr(sic),
+                                          _ptr(jiT), _ptr(keep), _ptr(why)))
+        return jiT, keep, why
+
+    def cart2geo(self, yx, lat0=70., lon0=-45.):
+        yx = as_c(yx, np.float64)
+        out = np.empty_like(yx)
+        self._chk(self._L.sitrk_cart2geo(self._h, yx.shape[0], _ptr(yx), float(lat0), float(lon0), _ptr(out)))
+        return out
+
+    def geo2cart(self, latlon, lat0=70., lon0=-45.):
+        g = as_c(latlon, np.float64)
+        out = np.empty_like(g)
+        self._chk(self._L.sitrk_geo2cart(self._h, g.shape[0], _ptr(g), float(lat0), float(lon0), _ptr(out)))
+        return out
+
+    # -- measurement
+    def timer_start(self):
+        self._chk(self._L.sitrk_timer_start(self._h))
+
+    def timer_stop(self):
+        ms = C.c_float(0)
+        self._chk(self._L.sitrk_timer_stop(self._h, C.byref(ms)))
+        return ms.value

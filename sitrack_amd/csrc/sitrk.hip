@@ -1,0 +1,589 @@
+// sitrk.hip -- C ABI of libsitrk.so (see include/sitrk.h) and kernel launches.
+// MI355X / gfx950 only.  No CPU fallback: every entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/sitrk.h"
+#include "sitrk_internal.h"
+#include "sitrk_kernels.h"
+
+using namespace sitrk;
+
+#define SITRK_API extern "C" __attribute__((visibility("default")))
+
+static thread_local char g_create_err[512] = {0};
+
+static int fail(sitrk_ctx *h, int code, const char *fmt, ...)
+{
+    char *dst = h ? h->err : g_create_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) return fail(h, SITRK_EHIP, "%s -> %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+#define NEED(cond, msg)                                \
+    do {                                               \
+        if (!(cond)) return fail(h, SITRK_EINVAL, msg); \
+    } while (0)
+
+static inline unsigned nblocks(int64_t n, int bs = kBlock) { return (unsigned)((n + bs - 1) / bs); }
+
+template <typename T>
+static hipError_t dev_alloc(T **p, size_t count)
+{
+    return hipMalloc((void **)p, count ? count * sizeof(T) : sizeof(T));
+}
+
+static void dev_free(void *p)
+{
+    if (p) (void)hipFree(p);
+}
+
+static int ensure_scratch(sitrk_ctx *h, size_t bytes)
+{
+    if (h->scratch_bytes >= bytes) return SITRK_OK;
+    dev_free(h->scratch);
+    h->scratch = nullptr;
+    h->scratch_bytes = 0;
+    HIPCHK(hipMalloc(&h->scratch, bytes));
+    h->scratch_bytes = bytes;
+    return SITRK_OK;
+}
+
+static void free_buoys(sitrk_ctx *h)
+{
+    for (int b = 0; b < 2; b++) {
+        dev_free(h->st[b].pos); dev_free(h->st[b].cell); dev_free(h->st[b].kill_rec);
+        dev_free(h->st[b].first); dev_free(h->st[b].last); dev_free(h->st[b].perm);
+        h->st[b] = BuoyState();
+        dev_free(h->keys[b]); dev_free(h->vals[b]);
+        h->keys[b] = nullptr; h->vals[b] = nullptr;
+    }
+    dev_free(h->sort_tmp);
+    h->sort_tmp = nullptr; h->sort_tmp_bytes = 0;
+    h->nP = 0;
+}
+
+// --------------------------------------------------------------------------- context
+SITRK_API int sitrk_version(void) { return SITRK_VERSION; }
+
+SITRK_API const char *sitrk_last_error(sitrk_t *h) { return h ? h->err : g_create_err; }
+
+SITRK_API int sitrk_create(sitrk_t **out, int device)
+{
+    sitrk_ctx *h = nullptr;
+    if (!out) return fail(h, SITRK_EINVAL, "sitrk_create: null output pointer");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(h, SITRK_EHIP, "sitrk_create: no HIP device (%s); libsitrk has no CPU path",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(h, SITRK_EINVAL, "sitrk_create: device %d out of range [0,%d)", device, ndev);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(h, SITRK_EHIP, "hipSetDevice(%d) -> %s", device, hipGetErrorString(e));
+    sitrk_ctx *c = new (std::nothrow) sitrk_ctx();
+    if (!c) return fail(h, SITRK_ENOMEM, "sitrk_create: out of host memory");
+    c->device = device;
+    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
+        (e = hipMalloc((void **)&c->counter, sizeof(unsigned long long))) != hipSuccess) {
+        int rc = fail(h, SITRK_EHIP, "sitrk_create: %s", hipGetErrorString(e));
+        delete c;
+        return rc;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return SITRK_OK;
+}
+
+SITRK_API int sitrk_destroy(sitrk_t *h)
+{
+    if (!h) return SITRK_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    free_buoys(h);
+    dev_free(h->geo); dev_free(h->tmask); dev_free(h->slabs); dev_free(h->scratch); dev_free(h->counter);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return SITRK_OK;
+}
+
+SITRK_API int sitrk_sync(sitrk_t *h)
+{
+    NEED(h, "null handle");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SITRK_OK;
+}
+
+SITRK_API int sitrk_set_stream(sitrk_t *h, void *hip_stream)
+{
+    NEED(h, "null handle");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return SITRK_OK;
+}
+
+// --------------------------------------------------------------------------- grid
+SITRK_API int sitrk_set_grid(sitrk_t *h, int Nj, int Ni, const double *Yf, const double *Xf, const double *Yu,
+                             const double *Xu, const double *Yv, const double *Xv, const int8_t *tmask)
+{
+    NEED(h, "null handle");
+    NEED(Yf && Xf && Yu && Xu && Yv && Xv && tmask, "sitrk_set_grid: null array");
+    if (Nj < 4 || Nj > 32767 || Ni < 4 || Ni > 65535)
+        return fail(h, SITRK_EINVAL, "sitrk_set_grid: grid %dx%d outside 4..32767 x 4..65535", Nj, Ni);
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    dev_free(h->geo); dev_free(h->tmask); dev_free(h->slabs);
+    h->geo = nullptr; h->tmask = nullptr; h->slabs = nullptr; h->nslots = 0;
+    free_buoys(h);
+    const size_t n = (size_t)Nj * Ni;
+    HIPCHK(dev_alloc(&h->geo, n));
+    HIPCHK(dev_alloc(&h->tmask, n));
+    // stage the six arrays in scratch, interleave on the device
+    int rc = ensure_scratch(h, 6 * n * sizeof(double));
+    if (rc) return rc;
+    double *s = (double *)h->scratch;
+    const double *src[6] = {Yf, Xf, Yu, Xu, Yv, Xv};
+    for (int a = 0; a < 6; a++) HIPCHK(hipMemcpyAsync(s + a * n, src[a], n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->tmask, tmask, n, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(build_geo_kernel, dim3(nblocks((int64_t)n)), dim3(kBlock), 0, h->stream, n, s, s + n, s + 2 * n, s + 3 * n,
+                       s + 4 * n, s + 5 * n, h->geo);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->Nj = Nj; h->Ni = Ni;
+    return SITRK_OK;
+}
+
+SITRK_API int sitrk_set_params(sitrk_t *h, double rdt, int uv_strategy, double rmin_conc)
+{
+    NEED(h, "null handle");
+    NEED(uv_strategy == 0 || uv_strategy == 1, "sitrk_set_params: uv_strategy must be 0 (cell mean) or 1 (nearest U/V point)");
+    NEED(rdt > 0.0, "sitrk_set_params: rdt must be > 0");
+    h->rdt = rdt; h->uv_strategy = uv_strategy; h->rmin_conc = rmin_conc;
+    return SITRK_OK;
+}
+
+// --------------------------------------------------------------------------- records
+static inline size_t elem_size(int dtype) { return dtype == SITRK_F64 ? 8 : 4; }
+
+SITRK_API int sitrk_alloc_records(sitrk_t *h, int nslots, int dtype)
+{
+    NEED(h, "null handle");
+    NEED(h->geo, "sitrk_alloc_records: call sitrk_set_grid first");
+    NEED(nslots >= 1 && nslots <= 4096, "sitrk_alloc_records: nslots out of range");
+    NEED(dtype == SITRK_F32 || dtype == SITRK_F64, "sitrk_alloc_records: dtype must be SITRK_F32 or SITRK_F64");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    dev_free(h->slabs);
+    h->slabs = nullptr; h->nslots = 0;
+    h->slab_bytes = 3 * (size_t)h->Nj * h->Ni * elem_size(dtype);
+    HIPCHK(hipMalloc(&h->slabs, h->slab_bytes * nslots));
+    h->nslots = nslots; h->dtype = dtype;
+    return SITRK_OK;
+}
+
+SITRK_API void *sitrk_record_ptr(sitrk_t *h, int slot)
+{
+    if (!h || !h->slabs || slot < 0 || slot >= h->nslots) return nullptr;
+    return (char *)h->slabs + (size_t)slot * h->slab_bytes;
+}
+
+SITRK_API int sitrk_push_record(sitrk_t *h, int slot, const void *u, const void *v, const void *sic)
+{
+    NEED(h, "null handle");
+    NEED(h->slabs, "sitrk_push_record: call sitrk_alloc_records first");
+    NEED(slot >= 0 && slot < h->nslots, "sitrk_push_record: slot out of range");
+    NEED(u && v && sic, "sitrk_push_record: null field");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t nb = h->slab_bytes / 3;
+    char *d = (char *)sitrk_record_ptr(h, slot);
+    HIPCHK(hipMemcpyAsync(d, u, nb, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d + nb, v, nb, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d + 2 * nb, sic, nb, hipMemcpyHostToDevice, h->stream));
+    return SITRK_OK;
+}
+
+SITRK_API int sitrk_push_record_dev(sitrk_t *h, int slot, const void *slab_dev)
+{
+    NEED(h, "null handle");
+    NEED(h->slabs, "sitrk_push_record_dev: call sitrk_alloc_records first");
+    NEED(slot >= 0 && slot < h->nslots, "sitrk_push_record_dev: slot out of range");
+    NEED(slab_dev, "sitrk_push_record_dev: null slab");
+    HIPCHK(hipSetDevice(h->device));
+    void *d = sitrk_record_ptr(h, slot);
+    if (d != slab_dev) HIPCHK(hipMemcpyAsync(d, slab_dev, h->slab_bytes, hipMemcpyDeviceToDevice, h->stream));
+    return SITRK_OK;
+}
+
+// --------------------------------------------------------------------------- buoys
+SITRK_API int sitrk_set_buoys(sitrk_t *h, int64_t nP, const double *yx, const int32_t *jiT, const int32_t *rec_first,
+                              const int32_t *rec_last)
+{
+    NEED(h, "null handle");
+    NEED(h->geo, "sitrk_set_buoys: call sitrk_set_grid first");
+    NEED(nP >= 0 && nP < 2147483647LL, "sitrk_set_buoys: nP out of range");
+    NEED(nP == 0 || (yx && jiT), "sitrk_set_buoys: null array");
+    NEED((rec_first == nullptr) == (rec_last == nullptr), "sitrk_set_buoys: rec_first and rec_last go together");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    free_buoys(h);
+    h->windowed = (rec_first != nullptr);
+    h->cur = 0; h->steps_since_sort = 0; h->sorted_once = false;
+    // host-side validation + packing of the host cell
+    std::vector<int32_t> packed((size_t)nP);
+    for (int64_t p = 0; p < nP; p++) {
+        int j = jiT[2 * p], i = jiT[2 * p + 1];
+        if (j < 1 || j > h->Nj - 2 || i < 1 || i > h->Ni - 2)
+            return fail(h, SITRK_EINDEX, "sitrk_set_buoys: buoy %lld host cell (%d,%d) outside 1..%d x 1..%d "
+                        "(the reference would index out of range)", (long long)p, j, i, h->Nj - 2, h->Ni - 2);
+        packed[(size_t)p] = pack_cell(j, i);
+    }
+    for (int b = 0; b < 2; b++) {
+        HIPCHK(dev_alloc(&h->st[b].pos, (size_t)nP));
+        HIPCHK(dev_alloc(&h->st[b].cell, (size_t)nP));
+        HIPCHK(dev_alloc(&h->st[b].kill_rec, (size_t)nP));
+        HIPCHK(dev_alloc(&h->st[b].perm, (size_t)nP));
+        if (h->windowed) {
+            HIPCHK(dev_alloc(&h->st[b].first, (size_t)nP));
+            HIPCHK(dev_alloc(&h->st[b].last, (size_t)nP));
+        }
+        HIPCHK(dev_alloc(&h->keys[b], (size_t)nP));
+        HIPCHK(dev_alloc(&h->vals[b], (size_t)nP));
+    }
+    h->nP = nP;
+    if (nP == 0) return SITRK_OK;
+    BuoyState &s = h->st[0];
+    HIPCHK(hipMemcpyAsync(s.pos, yx, (size_t)nP * sizeof(pt), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(s.cell, packed.data(), (size_t)nP * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(s.kill_rec, 0xff, (size_t)nP * 4, h->stream));          // -1
+    hipLaunchKernelGGL(iota_kernel, dim3(nblocks(nP)), dim3(kBlock), 0, h->stream, nP, s.perm);
+    HIPCHK(hipGetLastError());
+    if (h->windowed) {
+        HIPCHK(hipMemcpyAsync(s.first, rec_first, (size_t)nP * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(s.last, rec_last, (size_t)nP * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));      // `packed` must outlive the copy
+    return SITRK_OK;
+}
+
+SITRK_API int sitrk_set_resort(sitrk_t *h, int resort_every)
+{
+    NEED(h, "null handle");
+    NEED(resort_every >= 0, "sitrk_set_resort: resort_every must be >= 0");
+    h->resort_every = resort_every;
+    return SITRK_OK;
+}
+
+SITRK_API int sitrk_sort_buoys(sitrk_t *h)
+{
+    NEED(h, "null handle");
+    NEED(h->st[0].pos, "sitrk_sort_buoys: call sitrk_set_buoys first");
+    const int64_t nP = h->nP;
+    h->steps_since_sort = 0;
+    if (nP <= 1) return SITRK_OK;
+    HIPCHK(hipSetDevice(h->device));
+    BuoyState &in = h->st[h->cur], &out = h->st[h->cur ^ 1];
+    const uint32_t dead_key = (uint32_t)h->Nj * (uint32_t)h->Ni;
+    unsigned end_bit = 1;
+    while (end_bit < 32 && (dead_key >> end_bit)) end_bit++;
+    hipLaunchKernelGGL(make_keys_kernel, dim3(nblocks(nP)), dim3(kBlock), 0, h->stream, nP, h->Ni, dead_key, in.cell, h->keys[0], h->vals[0]);
+    HIPCHK(hipGetLastError());
+    size_t need = 0;
+    HIPCHK(sort_pairs_u32(nullptr, &need, h->keys[0], h->keys[1], h->vals[0], h->vals[1], (size_t)nP, end_bit, h->stream));
+    if (need > h->sort_tmp_bytes) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        dev_free(h->sort_tmp);
+        h->sort_tmp = nullptr; h->sort_tmp_bytes = 0;
+        HIPCHK(hipMalloc(&h->sort_tmp, need));
+        h->sort_tmp_bytes = need;
+    }
+    size_t tb = h->sort_tmp_bytes;
+    HIPCHK(sort_pairs_u32(h->sort_tmp, &tb, h->keys[0], h->keys[1], h->vals[0], h->vals[1], (size_t)nP, end_bit, h->stream));
+    hipLaunchKernelGGL(permute_state_kernel, dim3(nblocks(nP)), dim3(kBlock), 0, h->stream, nP, h->vals[1], in, out, h->windowed);
+    HIPCHK(hipGetLastError());
+    h->cur ^= 1;
+    h->sorted_once = true;
+    return SITRK_OK;
+}
+
+template <typename FT>
+static void launch_step(sitrk_ctx *h, const StepArgs &a)
+{
+    dim3 grid(nblocks(a.nP)), block(kBlock);
+    if (h->uv_strategy == 1) {
+        if (h->windowed) hipLaunchKernelGGL((advect_step_kernel<FT, 1, true>), grid, block, 0, h->stream, a);
+        else hipLaunchKernelGGL((advect_step_kernel<FT, 1, false>), grid, block, 0, h->stream, a);
+    } else {
+        if (h->windowed) hipLaunchKernelGGL((advect_step_kernel<FT, 0, true>), grid, block, 0, h->stream, a);
+        else hipLaunchKernelGGL((advect_step_kernel<FT, 0, false>), grid, block, 0, h->stream, a);
+    }
+}
+
+SITRK_API int sitrk_step(sitrk_t *h, int slot, int jrec)
+{
+    NEED(h, "null handle");
+    NEED(h->st[0].pos, "sitrk_step: call sitrk_set_buoys first");
+    NEED(h->slabs, "sitrk_step: call sitrk_alloc_records first");
+    NEED(slot >= 0 && slot < h->nslots, "sitrk_step: slot out of range");
+    if (h->nP == 0) return SITRK_OK;
+    if (h->resort_every > 0 && h->steps_since_sort >= h->resort_every) {
+        int rc = sitrk_sort_buoys(h);
+        if (rc) return rc;
+    }
+    const size_t n = (size_t)h->Nj * h->Ni, es = elem_size(h->dtype);
+    const char *slab = (const char *)sitrk_record_ptr(h, slot);
+    BuoyState &s = h->st[h->cur];
+    StepArgs a;
+    a.nP = h->nP; a.Nj = h->Nj; a.Ni = h->Ni; a.jrec = jrec;
+    a.rdt = h->rdt; a.rmin_conc = h->rmin_conc;
+    a.geo = h->geo; a.tmask = h->tmask;
+    a.u = slab; a.v = slab + n * es; a.sic = slab + 2 * n * es;
+    a.pos = s.pos; a.cell = s.cell; a.kill_rec = s.kill_rec; a.first = s.first; a.last = s.last;
+    if (h->dtype == SITRK_F64) launch_step<double>(h, a);
+    else launch_step<float>(h, a);
+    HIPCHK(hipGetLastError());
+    h->steps_since_sort++;
+    return SITRK_OK;
+}
+
+SITRK_API int sitrk_run(sitrk_t *h, int slot0, int jrec0, int nsteps)
+{
+    NEED(h, "null handle");
+    NEED(nsteps >= 0, "sitrk_run: nsteps must be >= 0");
+    NEED(h->nslots > 0, "sitrk_run: call sitrk_alloc_records first");
+    NEED(slot0 >= 0 && slot0 < h->nslots, "sitrk_run: slot0 out of range");
+    for (int k = 0; k < nsteps; k++) {
+        int rc = sitrk_step(h, (slot0 + k) % h->nslots, jrec0 + k);
+        if (rc) return rc;
+    }
+    return SITRK_OK;
+}
+
+// --------------------------------------------------------------------------- fetch
+static inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+SITRK_API int sitrk_fetch(sitrk_t *h, double *yx, int32_t *jiT, int8_t *alive, int32_t *kill_rec)
+{
+    NEED(h, "null handle");
+    NEED(h->st[0].pos, "sitrk_fetch: call sitrk_set_buoys first");
+    const int64_t nP = h->nP;
+    if (nP == 0) return SITRK_OK;
+    HIPCHK(hipSetDevice(h->device));
+    const size_t b_yx = align256((size_t)nP * sizeof(pt)), b_ji = align256((size_t)nP * 8), b_al = align256((size_t)nP),
+                 b_kr = align256((size_t)nP * 4);
+    int rc = ensure_scratch(h, b_yx + b_ji + b_al + b_kr);
+    if (rc) return rc;
+    char *s = (char *)h->scratch;
+    pt *d_yx = yx ? (pt *)s : nullptr;
+    int32_t *d_ji = jiT ? (int32_t *)(s + b_yx) : nullptr;
+    int8_t *d_al = alive ? (int8_t *)(s + b_yx + b_ji) : nullptr;
+    int32_t *d_kr = kill_rec ? (int32_t *)(s + b_yx + b_ji + b_al) : nullptr;
+    hipLaunchKernelGGL(fetch_state_kernel, dim3(nblocks(nP)), dim3(kBlock), 0, h->stream, nP, h->st[h->cur], d_yx, d_ji, d_al, d_kr);
+    HIPCHK(hipGetLastError());
+    if (yx) HIPCHK(hipMemcpyAsync(yx, d_yx, (size_t)nP * sizeof(pt), hipMemcpyDeviceToHost, h->stream));
+    if (jiT) HIPCHK(hipMemcpyAsync(jiT, d_ji, (size_t)nP * 8, hipMemcpyDeviceToHost, h->stream));
+    if (alive) HIPCHK(hipMemcpyAsync(alive, d_al, (size_t)nP, hipMemcpyDeviceToHost, h->stream));
+    if (kill_rec) HIPCHK(hipMemcpyAsync(kill_rec, d_kr, (size_t)nP * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SITRK_OK;
+}
+
+static ProjParams make_proj(double lat0, double lon0)
+{
+    ProjParams pp;
+    const double f = 1.0 / 298.257223563;            // WGS84
+    pp.a = 6378137.0;
+    pp.e = std::sqrt(2.0 * f - f * f);
+    pp.lon0 = lon0;
+    const double phits = std::fabs(lat0) * (M_PI / 180.0);
+    if (std::fabs(phits - M_PI_2) < 1e-10) {
+        pp.akm1 = 2.0 / std::sqrt(std::pow(1 + pp.e, 1 + pp.e) * std::pow(1 - pp.e, 1 - pp.e));
+    } else {
+        double t = std::sin(phits);
+        double es = pp.e * t;
+        double tsfn = std::tan(0.5 * (M_PI_2 - phits)) / std::pow((1.0 - es) / (1.0 + es), 0.5 * pp.e);
+        pp.akm1 = std::cos(phits) / tsfn;
+        pp.akm1 /= std::sqrt(1.0 - es * es);
+    }
+    return pp;
+}
+
+SITRK_API int sitrk_fetch_record(sitrk_t *h, int jrec, double *yx_rec, int8_t *mask, double *latlon)
+{
+    NEED(h, "null handle");
+    NEED(h->st[0].pos, "sitrk_fetch_record: call sitrk_set_buoys first");
+    const int64_t nP = h->nP;
+    if (nP == 0) return SITRK_OK;
+    HIPCHK(hipSetDevice(h->device));
+    const size_t b_yx = align256((size_t)nP * sizeof(pt)), b_mk = align256((size_t)nP);
+    int rc = ensure_scratch(h, 2 * b_yx + b_mk);
+    if (rc) return rc;
+    char *s = (char *)h->scratch;
+    pt *d_yx = (pt *)s;
+    int8_t *d_mk = (int8_t *)(s + b_yx);
+    ll *d_ll = (ll *)(s + b_yx + b_mk);
+    hipLaunchKernelGGL(fetch_record_kernel, dim3(nblocks(nP)), dim3(kBlock), 0, h->stream, nP, jrec, h->st[h->cur], h->windowed, d_yx, d_mk);
+    HIPCHK(hipGetLastError());
+    if (latlon) {
+        hipLaunchKernelGGL(cart2geo_kernel, dim3(nblocks(nP)), dim3(kBlock), 0, h->stream, nP, make_proj(70., -45.), d_yx, d_ll);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(latlon, d_ll, (size_t)nP * sizeof(ll), hipMemcpyDeviceToHost, h->stream));
+    }
+    if (yx_rec) HIPCHK(hipMemcpyAsync(yx_rec, d_yx, (size_t)nP * sizeof(pt), hipMemcpyDeviceToHost, h->stream));
+    if (mask) HIPCHK(hipMemcpyAsync(mask, d_mk, (size_t)nP, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SITRK_OK;
+}
+
+SITRK_API int sitrk_count_alive(sitrk_t *h, int64_t *nalive)
+{
+    NEED(h, "null handle");
+    NEED(nalive, "sitrk_count_alive: null output");
+    *nalive = 0;
+    if (h->nP == 0) return SITRK_OK;
+    NEED(h->st[0].pos, "sitrk_count_alive: call sitrk_set_buoys first");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemsetAsync(h->counter, 0, sizeof(unsigned long long), h->stream));
+    hipLaunchKernelGGL(count_alive_kernel, dim3(nblocks(h->nP)), dim3(kBlock), 0, h->stream, h->nP, h->st[h->cur].cell, h->counter);
+    HIPCHK(hipGetLastError());
+    unsigned long long v = 0;
+    HIPCHK(hipMemcpyAsync(&v, h->counter, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *nalive = (int64_t)v;
+    return SITRK_OK;
+}
+
+// --------------------------------------------------------------------------- locate
+SITRK_API int sitrk_find_cells(sitrk_t *h, int64_t n, const double *yx, const int32_t *jiT_guess, int32_t *jiT_out, int8_t *found)
+{
+    NEED(h, "null handle");
+    NEED(h->geo, "sitrk_find_cells: call sitrk_set_grid first");
+    NEED(n >= 0, "sitrk_find_cells: n < 0");
+    if (n == 0) return SITRK_OK;
+    NEED(yx && jiT_guess && jiT_out && found, "sitrk_find_cells: null array");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t b_yx = align256((size_t)n * sizeof(pt)), b_ji = align256((size_t)n * 8), b_f = align256((size_t)n);
+    int rc = ensure_scratch(h, b_yx + 2 * b_ji + b_f);
+    if (rc) return rc;
+    char *s = (char *)h->scratch;
+    pt *d_yx = (pt *)s;
+    int32_t *d_g = (int32_t *)(s + b_yx), *d_o = (int32_t *)(s + b_yx + b_ji);
+    int8_t *d_f = (int8_t *)(s + b_yx + 2 * b_ji);
+    HIPCHK(hipMemcpyAsync(d_yx, yx, (size_t)n * sizeof(pt), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_g, jiT_guess, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(find_cells_kernel, dim3(nblocks(n)), dim3(kBlock), 0, h->stream, n, h->Nj, h->Ni, h->geo, d_yx, d_g, d_o, d_f);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(jiT_out, d_o, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(found, d_f, (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SITRK_OK;
+}
+
+SITRK_API int sitrk_seed_init(sitrk_t *h, int64_t nP, const double *latlon, const double *yx, const double *latT,
+                              const double *lonT, const double *resolkm, const double *sic, int32_t *jiT_out, int8_t *keep,
+                              int8_t *why)
+{
+    NEED(h, "null handle");
+    NEED(h->geo, "sitrk_seed_init: call sitrk_set_grid first");
+    NEED(nP >= 0, "sitrk_seed_init: nP < 0");
+    if (nP == 0) return SITRK_OK;
+    NEED(latlon && yx && latT && lonT && sic && jiT_out && keep, "sitrk_seed_init: null array");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t n = (size_t)h->Nj * h->Ni;
+    const size_t b_pt = align256((size_t)nP * sizeof(pt)), b_g = align256(n * 8), b_ji = align256((size_t)nP * 8),
+                 b_k = align256((size_t)nP);
+    int rc = ensure_scratch(h, 2 * b_pt + 4 * b_g + b_ji + 2 * b_k);
+    if (rc) return rc;
+    char *s = (char *)h->scratch;
+    ll *d_ll = (ll *)s;                 s += b_pt;
+    pt *d_yx = (pt *)s;                 s += b_pt;
+    double *d_lat = (double *)s;        s += b_g;
+    double *d_lon = (double *)s;        s += b_g;
+    double *d_res = (double *)s;        s += b_g;
+    double *d_sic = (double *)s;        s += b_g;
+    int32_t *d_ji = (int32_t *)s;       s += b_ji;
+    int8_t *d_keep = (int8_t *)s;       s += b_k;
+    int8_t *d_why = (int8_t *)s;
+    HIPCHK(hipMemcpyAsync(d_ll, latlon, (size_t)nP * sizeof(ll), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_yx, yx, (size_t)nP * sizeof(pt), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_lat, latT, n * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_lon, lonT, n * 8, hipMemcpyHostToDevice, h->stream));
+    if (resolkm) HIPCHK(hipMemcpyAsync(d_res, resolkm, n * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_sic, sic, n * 8, hipMemcpyHostToDevice, h->stream));
+    // rFoundKM = 2.5 (tracking.py:5), max_itr = 10 (tracking.py:134)
+    hipLaunchKernelGGL(seed_init_bruteforce_kernel, dim3((unsigned)nP), dim3(kBlock), 0, h->stream, nP, h->Nj, h->Ni, d_ll, d_yx,
+                       d_lat, d_lon, resolkm ? d_res : nullptr, d_sic, h->tmask, h->geo, h->rmin_conc, 2.5, 10, d_ji, d_keep, d_why);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(jiT_out, d_ji, (size_t)nP * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(keep, d_keep, (size_t)nP, hipMemcpyDeviceToHost, h->stream));
+    if (why) HIPCHK(hipMemcpyAsync(why, d_why, (size_t)nP, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SITRK_OK;
+}
+
+// --------------------------------------------------------------------------- projection
+static int project(sitrk_ctx *h, int64_t n, const double *in, double lat0, double lon0, double *out, bool inverse)
+{
+    NEED(h, "null handle");
+    NEED(n >= 0, "projection: n < 0");
+    if (n == 0) return SITRK_OK;
+    NEED(in && out, "projection: null array");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t b = align256((size_t)n * 16);
+    int rc = ensure_scratch(h, 2 * b);
+    if (rc) return rc;
+    char *s = (char *)h->scratch;
+    HIPCHK(hipMemcpyAsync(s, in, (size_t)n * 16, hipMemcpyHostToDevice, h->stream));
+    ProjParams pp = make_proj(lat0, lon0);
+    if (inverse) hipLaunchKernelGGL(cart2geo_kernel, dim3(nblocks(n)), dim3(kBlock), 0, h->stream, n, pp, (const pt *)s, (ll *)(s + b));
+    else hipLaunchKernelGGL(geo2cart_kernel, dim3(nblocks(n)), dim3(kBlock), 0, h->stream, n, pp, (const ll *)s, (pt *)(s + b));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, s + b, (size_t)n * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SITRK_OK;
+}
+
+SITRK_API int sitrk_cart2geo(sitrk_t *h, int64_t n, const double *yx, double lat0, double lon0, double *latlon)
+{
+    return project(h, n, yx, lat0, lon0, latlon, true);
+}
+
+SITRK_API int sitrk_geo2cart(sitrk_t *h, int64_t n, const double *latlon, double lat0, double lon0, double *yx)
+{
+    return project(h, n, latlon, lat0, lon0, yx, false);
+}
+
+// --------------------------------------------------------------------------- measurement
+SITRK_API int sitrk_timer_start(sitrk_t *h)
+{
+    NEED(h, "null handle");
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    return SITRK_OK;
+}
+
+SITRK_API int sitrk_timer_stop(sitrk_t *h, float *ms)
+{
+    NEED(h, "null handle");
+    NEED(ms, "sitrk_timer_stop: null output");
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    HIPCHK(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return SITRK_OK;
+}

@@ -1,0 +1,70 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every
+symbol include/sitrk.h declares, and fails loudly without a GPU (no CPU fallback)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import sitrack_amd as sit
+from sitrack_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "sitrk.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sitrk_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    so = _lib.build()
+    assert os.path.exists(so)
+    names = declared_symbols()
+    assert len(names) >= 20
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (sitrk_[a-z0-9_]+)", out))
+    assert set(names) <= exported, sorted(set(names) - exported)
+    # nothing but the C ABI is exported
+    assert all(s.startswith("sitrk_") for s in re.findall(r" T (\S+)", out))
+    # the ctypes binding covers exactly the header
+    assert sorted(_lib._SIGNATURES) == names
+    L = _lib.lib()
+    assert L.sitrk_version() == 100
+
+
+def test_no_cpu_fallback_without_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(sit.SitrkError, match="no HIP device"):
+        sit.Context(0)
+    with pytest.raises(sit.SitrkError):
+        sit.CartNPSkm2Geo1D(np.zeros((3, 2)))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "sitrack_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.lower(), os.path.join(dirpath, f)
+
+
+def test_get_time_span_matches_golden(golden):
+    g = golden("g8_timespan.npz")
+    vt = g["vtime"]
+    for c in g["cases"]:
+        sd, stop = int(c[0]), (None if c[1] < 0 else int(c[1]))
+        got = sit.GetTimeSpan(3600., vt, sd, vt[0], vt[-1], iStop=stop)
+        assert tuple(int(x) for x in got) == tuple(int(x) for x in c[2:])
+    with pytest.raises(ValueError):
+        sit.GetTimeSpan(3600., vt, int(vt[0]) - 7200, vt[0], vt[-1])
+
+
+def test_vertices_are_a_function_of_the_cell(golden):
+    g = golden("g5_seedinit.npz")
+    assert np.array_equal(sit.vertices_of(g["ojiT"]), g["overt"])
