@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-steps/s of the per-buoy advection hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one model record applied to every buoy of the batch (one launch of
+advect_step_kernel per rank).  Workload at N=1 = BASELINE.json configs[2] (C3,
+the one the metric is quoted on): synthetic regular 4096x4096 C-grid (4 km),
+1e7 random buoys in the central 60 %, 8 device-resident fp32 records (solid-body
+rotation + per-record drift) cycled.  N>1: one process per GPU,
+each rank owns a contiguous range of 1e7 buoys of the N*1e7 set (weak scaling),
+the record slabs are generated on rank 0 and broadcast over RCCL into every
+rank's resident slots (the path's only exchange step); stepping needs no
+collective.
+
+Prints ONE JSON line (rank 0).  `roofline.achieved` uses the ALGORITHMIC bytes
+of SURVEY.md 8(d), A = 50*nP + 56*Nj*Ni per step, over the average step duration
+measured with HIP events on the library's own stream.  `cpu_baseline` = the CPU
+oracle (oracle/sitrk_oracle.c, a port of the reference loop, OpenMP over buoys)
+timed on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured achievable
+
+CONFIGS = {
+    # name: (Nj, Ni, buoys per GPU, label)
+    "c3": (4096, 4096, 10_000_000, "C3: synthetic 4096x4096 C-grid, 1e7 buoys/GPU, fp32 records"),
+    "c2": (512, 512, 100_000, "C2: synthetic 512x512 C-grid, 1e5 buoys/GPU, fp32 records"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--records", type=int, default=8, help="device-resident records cycled")
+    ap.add_argument("--resort", type=int, default=-1, help="re-sort buoys by cell every R steps (0 never, -1 default)")
+    ap.add_argument("--uv-strategy", type=int, default=1)
+    ap.add_argument("--no-sort", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--check", action="store_true", help="verify a subsample against the oracle after the run")
+    return ap.parse_args()
+
+
+def cpu_baseline(grid, u, v, sic, yx, ji, target_s, uv_strategy):
+    """Oracle on host cores: bounded sample of the same workload (first nS buoys x a few records)."""
+    from oracle import oracle as orc
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    K = u.shape[0]
+    f64 = [(u[k].astype(np.float64), v[k].astype(np.float64), sic[k].astype(np.float64)) for k in range(min(K, 2))]
+    out = {}
+    for nthreads, nS in ((1, min(len(yx), 200_000)), (cores, min(len(yx), 2_000_000))):
+        trk = orc.Tracker(grid, yx[:nS], ji[:nS], uv_strategy=uv_strategy, nthreads=nthreads)
+        trk.step(0, *f64[0], want_out=False)                     # warm
+        t0 = time.perf_counter()
+        nrec = 0
+        while True:
+            trk.step(1 + nrec, *f64[nrec % len(f64)], want_out=False)
+            nrec += 1
+            if time.perf_counter() - t0 > target_s / 2 or nrec >= 200:
+                break
+        dt = time.perf_counter() - t0
+        out[nthreads] = (nS * nrec / dt, nS, nrec)
+    rate, nS, nrec = out[cores]
+    return {"value": rate, "unit": "particle-steps/s", "cores": cores, "kind": "port",
+            "sample": "first %d buoys x %d records of the same workload, fp64 oracle with OpenMP over buoys" % (nS, nrec),
+            "value_1core": out[1][0], "sample_1core": "%d buoys x %d records" % (out[1][1], out[1][2])}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+
+    import torch
+    import sitrack_amd as sit
+    from sitrack_amd import synthetic as syn
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+
+    Nj, Ni, nP, label = CONFIGS[a.config]
+    K = a.records
+    grid = syn.make_grid(Nj, Ni, dkm=4.0, warp=0.0)
+    # buoys: rank r owns the r-th contiguous range of the world*nP set
+    _, yx = syn.make_buoys(grid, nP, seed=1234 + rank, frac=0.6)
+    ji = syn.regular_host_cell(grid, yx).astype(np.int32)
+
+    ctx = sit.Context(local_rank)
+    ctx.set_grid(grid["Yf"], grid["Xf"], grid["Yu"], grid["Xu"], grid["Yv"], grid["Xv"], grid["tmask"])
+    ctx.set_params(3600., a.uv_strategy, 0.1)
+    ctx.alloc_records(K, np.float32)
+
+    # host cells through the product's own FindContainingCell (also validates the analytic guess)
+    found, ji2 = ctx.find_cells(yx, ji)
+    assert found.all() and np.array_equal(ji2, ji), "host-cell seeding failed"
+
+    # records: generated on rank 0, broadcast over RCCL into each rank's resident slots
+    u = v = sic = None
+    if rank == 0:
+        u, v, sic = syn.make_fields(grid, K=K, seed=2024, umax=0.3, drift=0.05)
+    if world > 1:
+        for k in range(K):
+            slab = torch.empty(ctx.slab_elems, dtype=torch.float32, device="cuda")
+            if rank == 0:
+                slab.copy_(torch.from_numpy(np.concatenate([u[k].ravel(), v[k].ravel(), sic[k].ravel()])))
+            dist.broadcast(slab, src=0)
+            torch.cuda.synchronize()
+            ctx.push_record_dev(k, slab.data_ptr())
+            ctx.sync()
+            del slab
+    else:
+        for k in range(K):
+            ctx.push_record(k, u[k], v[k], sic[k])
+
+    ctx.set_buoys(yx, ji, sort=not a.no_sort)
+    resort = a.resort if a.resort >= 0 else 0
+    ctx.set_resort(0 if a.no_sort else resort)
+
+    def barrier():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    ctx.run(0, 0, a.warmup)
+    barrier()
+    ctx.timer_start()
+    t0 = time.perf_counter()
+    ctx.run(a.warmup % K, a.warmup, a.steps)
+    ev_ms = ctx.timer_stop()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt, ev_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, ev_ms = float(t[0]), float(t[1])
+
+    nalive = ctx.count_alive()
+    if dist is not None:
+        t = torch.tensor([nalive], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t)
+        nalive = int(t[0])
+
+    if a.check and rank == 0:
+        from oracle import oracle as orc
+        nS = 20000
+        ref = orc.Tracker(grid, yx[:nS], ji[:nS], uv_strategy=a.uv_strategy, nthreads=8)
+        for s in range(a.warmup + a.steps):
+            k = s % K
+            ref.step(s, u[k].astype(np.float64), v[k].astype(np.float64), sic[k].astype(np.float64), want_out=False)
+        st = ctx.fetch()
+        assert np.array_equal(st["yx"][:nS], ref.pos) and np.array_equal(st["jiT"][:nS], ref.jiT)
+        assert np.array_equal(st["alive"][:nS], ref.alive)
+        print("check OK: first %d buoys bit-exact vs oracle after %d steps" % (nS, a.warmup + a.steps), file=sys.stderr)
+
+    if rank == 0:
+        total = float(nP) * world * a.steps
+        step_s = (ev_ms / 1e3) / a.steps                     # avg launch duration, HIP events, library stream
+        A = 50.0 * nP + 56.0 * Nj * Ni                       # algorithmic bytes per step per GPU
+        achieved = A / step_s / 1e9
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tj):
+            try:
+                traffic = json.load(open(tj)).get(a.config, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "particle-steps/s", "value": total / dt, "unit": "particle-steps/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": label, "grid": [Nj, Ni], "buoys_per_gpu": nP, "buoys_total": nP * world,
+                       "records_resident": K, "record_dtype": "f32", "uv_strategy": a.uv_strategy,
+                       "sorted": not a.no_sort, "resort_every": 0 if a.no_sort else resort,
+                       "partition": "buoy-range x%d" % world, "alive_after": nalive},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": A, "kernel": "advect_step_kernel",
+                         "avg_launch_ms": 1e3 * step_s},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(grid, u, v, sic, yx, ji, a.cpu_seconds, a.uv_strategy)
+        print(json.dumps(line))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

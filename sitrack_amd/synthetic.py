@@ -89,6 +89,16 @@ def nearest_t_guess(grid, yx):
     return np.stack([np.clip(j, 2, Nj - 3), np.clip(i, 2, Ni - 3)], axis=1)
 
 
+def nearest_t_plane(grid, yx):
+    """Nearest T-point in the (y,x) plane (k-d tree): a good FindContainingCell guess on warped grids."""
+    from scipy.spatial import cKDTree
+    Nj, Ni = grid["Nj"], grid["Ni"]
+    tree = cKDTree(np.stack([grid["Yt"].ravel(), grid["Xt"].ravel()], axis=1))
+    _, k = tree.query(yx)
+    j, i = np.unravel_index(k, (Nj, Ni))
+    return np.stack([np.clip(j, 2, Nj - 3), np.clip(i, 2, Ni - 3)], axis=1).astype(np.int64)
+
+
 def make_buoys(grid, nP, seed=1234, frac=0.6):
     """Uniform random buoys in the central `frac` of the domain; IDs 1..nP (int64)."""
     rng = np.random.default_rng(seed)

@@ -66,7 +66,7 @@ def test_random_cloud_vs_oracle(warp, field_dtype):
     _, yx = syn.make_buoys(grid, nP, seed=5, frac=0.8)
     trk = make_tracker(grid, tmask, K, field_dtype=field_dtype)
     try:
-        guess = syn.nearest_t_guess(grid, yx).astype(np.int32)
+        guess = syn.nearest_t_plane(grid, yx).astype(np.int32)
         found, ji, _ = sit.FindContainingCell(yx, guess, ctx=trk.ctx)
         # the oracle's FindContainingCell agrees buoy by buoy
         for b in range(0, nP, 997):
@@ -106,7 +106,8 @@ def test_run_many_steps_equals_stepping(ctx):
     res = []
     for mode in ("run", "step"):
         trk = make_tracker(grid, grid["tmask"], 3)
-        found, ji, _ = sit.FindContainingCell(yx, syn.nearest_t_guess(grid, yx), ctx=trk.ctx)
+        found, ji, _ = sit.FindContainingCell(yx, syn.nearest_t_plane(grid, yx), ctx=trk.ctx)
+        assert found.mean() > 0.9
         trk.set_buoys(yx[found], ji[found])
         for k in range(3):
             trk.load_record(k, u[k], v[k], sic[k])
