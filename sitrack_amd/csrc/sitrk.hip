@@ -2,6 +2,7 @@
 // MI355X / gfx950 only.  No CPU fallback: every entry point needs a HIP device.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -461,7 +462,7 @@ SITRK_API int sitrk_count_alive(sitrk_t *h, int64_t *nalive)
     NEED(h->st[0].pos, "sitrk_count_alive: call sitrk_set_buoys first");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemsetAsync(h->counter, 0, sizeof(unsigned long long), h->stream));
-    hipLaunchKernelGGL(count_alive_kernel, dim3(nblocks(h->nP)), dim3(kBlock), 0, h->stream, h->nP, h->st[h->cur].cell, h->counter);
+    hipLaunchKernelGGL(count_alive_kernel, dim3(std::min(nblocks(h->nP), 2048u)), dim3(kBlock), 0, h->stream, h->nP, h->st[h->cur].cell, h->counter);
     HIPCHK(hipGetLastError());
     unsigned long long v = 0;
     HIPCHK(hipMemcpyAsync(&v, h->counter, sizeof(v), hipMemcpyDeviceToHost, h->stream));

@@ -235,12 +235,21 @@ __global__ void fetch_record_kernel(int64_t n, int jrec, BuoyState st, bool wind
     if (mask) mask[o] = stepped ? 1 : 0;
 }
 
-__global__ void count_alive_kernel(int64_t n, const int32_t *__restrict__ cell, unsigned long long *out)
+__global__ __launch_bounds__(kBlock) void count_alive_kernel(int64_t n, const int32_t *__restrict__ cell, unsigned long long *out)
 {
-    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool live = (s < n) && (cell[s] >= 0);
-    unsigned long long m = __ballot(live);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
+    // grid-stride count, wave ballot, one atomic per workgroup (same-address atomics serialise at the memory side)
+    __shared__ unsigned int sw[kBlock / 64];
+    unsigned int cnt = 0;
+    for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < n; s += (int64_t)gridDim.x * kBlock)
+        cnt += (cell[s] >= 0) ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int t = 0;
+        for (int w = 0; w < kBlock / 64; w++) t += sw[w];
+        if (t) atomicAdd(out, (unsigned long long)t);
+    }
 }
 
 // ---------------------------------------------------------------------------
