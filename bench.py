@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--check", action="store_true", help="verify a subsample against the oracle after the run")
+    ap.add_argument("--regime", default="resident", choices=["resident", "e2e"],
+                    help="resident: records live in HBM (the metric). e2e: every step's record is uploaded from pinned host "
+                         "memory on rank 0 (+ RCCL broadcast), double-buffered against the stepping; reported for context only")
     return ap.parse_args()
 
 
@@ -63,6 +66,7 @@ def cpu_baseline(grid, u, v, sic, yx, ji, target_s, uv_strategy):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    cores = min(cores, 16)      # the GPU box's CPU share for one GPU is 16 cores
     K = u.shape[0]
     f64 = [(u[k].astype(np.float64), v[k].astype(np.float64), sic[k].astype(np.float64)) for k in range(min(K, 2))]
     out = {}
@@ -120,23 +124,21 @@ def main():
     found, ji2 = ctx.find_cells(yx, ji)
     assert found.all() and np.array_equal(ji2, ji), "host-cell seeding failed"
 
-    # records: generated on rank 0, broadcast over RCCL into each rank's resident slots
+    from sitrack_amd import distributed as sd
+
+    # records: generated on rank 0; every rank receives them by ONE RCCL broadcast per record, written
+    # in place into its resident slot (the path's only exchange step).  No collective while stepping.
     u = v = sic = None
+    slabs_host = None
     if rank == 0:
         u, v, sic = syn.make_fields(grid, K=K, seed=2024, umax=0.3, drift=0.05)
-    if world > 1:
+        slabs_host = [sd.pack_slab(u[k], v[k], sic[k], np.float32) for k in range(K)]
+    if a.regime == "resident":
         for k in range(K):
-            slab = torch.empty(ctx.slab_elems, dtype=torch.float32, device="cuda")
-            if rank == 0:
-                slab.copy_(torch.from_numpy(np.concatenate([u[k].ravel(), v[k].ravel(), sic[k].ravel()])))
-            dist.broadcast(slab, src=0)
-            torch.cuda.synchronize()
-            ctx.push_record_dev(k, slab.data_ptr())
-            ctx.sync()
-            del slab
-    else:
-        for k in range(K):
-            ctx.push_record(k, u[k], v[k], sic[k])
+            if world > 1:
+                sd.broadcast_record(ctx, k, slabs_host[k] if rank == 0 else None, src=0)
+            else:
+                ctx.push_record(k, u[k], v[k], sic[k])
 
     ctx.set_buoys(yx, ji, sort=not a.no_sort)
     resort = a.resort if a.resort >= 0 else 0
@@ -148,14 +150,56 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    ctx.run(0, 0, a.warmup)
-    barrier()
-    ctx.timer_start()
-    t0 = time.perf_counter()
-    ctx.run(a.warmup % K, a.warmup, a.steps)
-    ev_ms = ctx.timer_stop()
-    barrier()
-    dt = time.perf_counter() - t0
+    if a.regime == "resident":
+        ctx.run(0, 0, a.warmup)
+        barrier()
+        ctx.timer_start()
+        t0 = time.perf_counter()
+        ctx.run(a.warmup % K, a.warmup, a.steps)
+        ev_ms = ctx.timer_stop()
+        barrier()
+        dt = time.perf_counter() - t0
+    else:
+        # end-to-end: record s goes pinned host -> slot s%2 on a copy stream (rank 0), is broadcast, and is
+        # consumed by step s on the compute stream; delivery of record s+1 overlaps step s.
+        assert K >= 2
+        comp, copy = torch.cuda.Stream(), torch.cuda.Stream()
+        ctx.set_stream(comp.cuda_stream)
+        slots = [sd.slot_tensor(ctx, 0), sd.slot_tensor(ctx, 1)]
+        pinned = [torch.from_numpy(x).pin_memory() for x in slabs_host] if rank == 0 else None
+        ready = [torch.cuda.Event(), torch.cuda.Event()]
+        free = [torch.cuda.Event(), torch.cuda.Event()]
+
+        def deliver(sidx):
+            b = sidx % 2
+            with torch.cuda.stream(copy):
+                copy.wait_event(free[b])
+                if rank == 0:
+                    slots[b].copy_(pinned[sidx % K], non_blocking=True)
+                if dist is not None:
+                    dist.broadcast(slots[b], src=0)
+                ready[b].record(copy)
+
+        def run_e2e(s0, n):
+            deliver(s0)
+            for sidx in range(s0, s0 + n):
+                if sidx + 1 < s0 + n:
+                    deliver(sidx + 1)
+                comp.wait_event(ready[sidx % 2])
+                ctx.step(sidx % 2, sidx)
+                free[sidx % 2].record(comp)
+
+        for e in free:
+            e.record(comp)
+        run_e2e(0, a.warmup)
+        barrier()
+        ctx.timer_start()
+        t0 = time.perf_counter()
+        run_e2e(a.warmup, a.steps)
+        ev_ms = ctx.timer_stop()
+        barrier()
+        dt = time.perf_counter() - t0
+        ctx.set_stream(None)
     if dist is not None:
         t = torch.tensor([dt, ev_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -198,7 +242,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": label, "grid": [Nj, Ni], "buoys_per_gpu": nP, "buoys_total": nP * world,
                        "records_resident": K, "record_dtype": "f32", "uv_strategy": a.uv_strategy,
-                       "sorted": not a.no_sort, "resort_every": 0 if a.no_sort else resort,
+                       "sorted": not a.no_sort, "resort_every": 0 if a.no_sort else resort, "regime": a.regime,
                        "partition": "buoy-range x%d" % world, "alive_after": nalive},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

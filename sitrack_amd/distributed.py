@@ -1,0 +1,97 @@
+"""Multi-GPU plumbing: one process per GPU, buoy-range partition, record broadcast.
+
+Buoys never interact (no term of reference si3_part_tracker.py:378-490 reads another
+buoy's state), so rank r owns the r-th contiguous range of the buoy arrays and steps it
+with its own context.  Geometry is replicated.  The path's single exchange step is the
+broadcast of each model record's `[u|v|siconc]` slab from the rank that ingested it
+(reference :372-374 reads it from NetCDF) -- `torch.distributed.broadcast`, backend
+"nccl" (= RCCL over xGMI) straight into the resident slot of libsitrk, or "gloo" on host
+arrays for CPU rehearsals.  Results are gathered back in the caller's buoy order.
+"""
+import numpy as np
+
+
+def buoy_range(nP, rank, world):
+    """Contiguous [lo,hi) of rank `rank`: sizes differ by at most one, order preserved."""
+    base, rem = divmod(int(nP), int(world))
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    return lo, hi
+
+
+def all_ranges(nP, world):
+    return [buoy_range(nP, r, world) for r in range(world)]
+
+
+class _DeviceSpan:
+    """Exposes a raw device pointer through __cuda_array_interface__ so that torch can
+    wrap libsitrk's record slot without a copy."""
+
+    def __init__(self, ptr, nelem, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(nelem),), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def slot_tensor(ctx, slot):
+    """torch view (1-D, 3*Nj*Ni elements) of a resident record slot of `ctx`."""
+    import torch
+    typestr = "<f8" if ctx.field_dtype == np.dtype(np.float64) else "<f4"
+    return torch.as_tensor(_DeviceSpan(ctx.record_ptr(slot), ctx.slab_elems, typestr), device="cuda:%d" % ctx.device)
+
+
+def pack_slab(u, v, sic, dtype):
+    """[u|v|siconc] as one contiguous 1-D array (the layout of a record slot)."""
+    return np.concatenate([np.ascontiguousarray(u, dtype=dtype).ravel(), np.ascontiguousarray(v, dtype=dtype).ravel(),
+                           np.ascontiguousarray(sic, dtype=dtype).ravel()])
+
+
+def broadcast_record(ctx, slot, slab_host, src=0, group=None, async_op=False):
+    """Broadcast one record slab into slot `slot` of every rank's context.
+
+    `slab_host`: packed [u|v|siconc] numpy array on rank `src`, ignored elsewhere.
+    With backend nccl the broadcast writes the resident slot directly (no staging copy).
+    Returns the torch work handle when async_op, else None (stream-synchronised)."""
+    import torch
+    import torch.distributed as dist
+    t = slot_tensor(ctx, slot)
+    if dist.get_rank(group) == src:
+        t.copy_(torch.from_numpy(slab_host), non_blocking=False)
+    work = dist.broadcast(t, src=src, group=group, async_op=async_op)
+    if async_op:
+        return work
+    torch.cuda.current_stream().synchronize()
+    return None
+
+
+def broadcast_record_host(slab_host, nelem, dtype, src=0, group=None):
+    """gloo rehearsal of the same exchange on host memory: returns the slab on every rank."""
+    import torch
+    import torch.distributed as dist
+    if dist.get_rank(group) == src:
+        t = torch.from_numpy(np.ascontiguousarray(slab_host, dtype=dtype))
+    else:
+        t = torch.from_numpy(np.empty(nelem, dtype=dtype))
+    dist.broadcast(t, src=src, group=group)
+    return t.numpy()
+
+
+def gather_ranges(local, nP, group=None, dst=0):
+    """Gather per-rank arrays (first axis = the rank's buoy range) back into caller order on `dst`.
+
+    Works with any backend (objects are small compared with the trajectories' size on the
+    path that uses it: the end-of-run fetch)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    parts = [None] * world if rank == dst else None
+    dist.gather_object(local, parts, dst=dst, group=group)
+    if rank != dst:
+        return None
+    out = np.concatenate(parts, axis=0)
+    assert out.shape[0] == nP
+    return out
+
+
+def split_slab(slab, Nj, Ni):
+    n = Nj * Ni
+    return slab[:n].reshape(Nj, Ni), slab[n:2 * n].reshape(Nj, Ni), slab[2 * n:3 * n].reshape(Nj, Ni)

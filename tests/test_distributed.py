@@ -1,0 +1,127 @@
+"""N>1 path on CPU: world_size-2 gloo rehearsal of the buoy-range partition, the per-record
+slab broadcast and the end-of-run gather.  The per-rank stepping is done here by the CPU
+oracle (the GPU kernels cannot run in this container); the exchange code is the product's."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from sitrack_amd import distributed as sd
+from sitrack_amd import synthetic as syn
+
+
+def test_buoy_ranges_cover_in_order():
+    for nP in (0, 1, 7, 8, 9, 1000, 10_000_001):
+        for world in (1, 2, 3, 8):
+            r = sd.all_ranges(nP, world)
+            assert r[0][0] == 0 and r[-1][1] == nP
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            sizes = [hi - lo for lo, hi in r]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_pack_and_split_slab():
+    rng = np.random.default_rng(0)
+    u, v, s = (rng.random((5, 7)).astype(np.float32) for _ in range(3))
+    slab = sd.pack_slab(u, v, s, np.float32)
+    assert slab.shape == (3 * 35,)
+    uu, vv, ss = sd.split_slab(slab, 5, 7)
+    assert np.array_equal(uu, u) and np.array_equal(vv, v) and np.array_equal(ss, s)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    from oracle import oracle as orc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        Nj, Ni, nP, K, Nt = 40, 48, 901, 3, 12
+        grid = syn.make_grid(Nj, Ni, dkm=4.0, warp=1.0)           # geometry replicated: every rank builds it
+        _, yx = syn.make_buoys(grid, nP, seed=9, frac=0.6)
+        guess = syn.nearest_t_plane(grid, yx)
+        ok = np.zeros(nP, dtype=bool); ji = np.zeros((nP, 2), dtype=np.int64)
+        for b in range(nP):
+            ok[b], ji[b], _ = orc.FindContainingCell(yx[b], guess[b], grid["Yf"], grid["Xf"])
+        yx, ji = yx[ok], ji[ok]
+        nP = len(yx)
+        lo, hi = sd.buoy_range(nP, rank, world)
+        mine = orc.Tracker(grid, yx[lo:hi], ji[lo:hi])
+        fields = syn.make_fields(grid, K=K, seed=4, umax=0.7, drift=0.2, ripple=0.1) if rank == 0 else None
+        for jrec in range(Nt):
+            slab = sd.pack_slab(fields[0][jrec % K], fields[1][jrec % K], fields[2][jrec % K], np.float32) if rank == 0 else None
+            slab = sd.broadcast_record_host(slab, 3 * Nj * Ni, np.float32, src=0)      # the path's only exchange
+            u, v, s = sd.split_slab(slab, Nj, Ni)
+            mine.step(jrec, u, v, s, want_out=False)
+        pos = sd.gather_ranges(mine.pos, nP)
+        cells = sd.gather_ranges(mine.jiT, nP)
+        alive = sd.gather_ranges(mine.alive, nP)
+        if rank == 0:
+            ref = orc.Tracker(grid, yx, ji)
+            for jrec in range(Nt):
+                ref.step(jrec, fields[0][jrec % K], fields[1][jrec % K], fields[2][jrec % K], want_out=False)
+            good = np.array_equal(pos, ref.pos) and np.array_equal(cells, ref.jiT) and np.array_equal(alive, ref.alive)
+            q.put(("ok" if good else "mismatch", int(ref.ncross)))
+    except Exception as e:                                           # pragma: no cover
+        if rank == 0:
+            q.put(("error: %r" % (e,), 0))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gloo_partition_broadcast_gather():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    status, ncross = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert status == "ok", status
+    assert ncross > 100
+
+
+@pytest.mark.gpu
+def test_slot_tensor_broadcast_world1_rccl():
+    """RCCL path on one GPU: the broadcast writes the resident slot in place."""
+    import torch
+    import torch.distributed as dist
+    import sitrack_amd as sit
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(_free_port()))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        grid = syn.make_grid(64, 64, dkm=4.0, warp=1.0)
+        u, v, s = syn.make_fields(grid, K=2, seed=1, umax=0.6, drift=0.2)
+        _, yx = syn.make_buoys(grid, 3000, seed=3)
+        outs = []
+        for mode in ("push", "bcast"):
+            trk = sit.IceTracker(grid["Yf"], grid["Xf"], grid["Yu"], grid["Xu"], grid["Yv"], grid["Xv"], grid["tmask"], nslots=2)
+            found, ji, _ = sit.FindContainingCell(yx, syn.nearest_t_plane(grid, yx), ctx=trk.ctx)
+            trk.set_buoys(yx[found], ji[found])
+            for k in range(2):
+                if mode == "push":
+                    trk.load_record(k, u[k], v[k], s[k])
+                else:
+                    sd.broadcast_record(trk.ctx, k, sd.pack_slab(u[k], v[k], s[k], np.float32), src=0)
+            trk.ctx.run(0, 0, 9)
+            outs.append(trk.state())
+            trk.close()
+        for key in ("yx", "vJIt", "iAlive"):
+            assert np.array_equal(outs[0][key], outs[1][key])
+    finally:
+        dist.destroy_process_group()
