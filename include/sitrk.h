@@ -74,6 +74,13 @@ int sitrk_set_grid(sitrk_t *h, int Nj, int Ni,
  * rmin_conc = 0.1 (sitrack/tracking.py:4) */
 int sitrk_set_params(sitrk_t *h, double rdt, int uv_strategy, double rmin_conc);
 
+/* performance knobs; they never change results.  "xcd_remap" (0/1): each XCD walks a
+ * contiguous chunk of the cell-sorted buoys; "nt_state" (0/1): non-temporal loads/stores for
+ * the once-per-step position/cell streams; "compact" (0/1): workgroup compaction of the
+ * cell-crossing path; "locate_bruteforce" (0/1): SeedInit scans the whole grid per seed like
+ * the reference instead of the bounding-sphere search. */
+int sitrk_set_tuning(sitrk_t *h, const char *knob, int value);
+
 /* ---- model records (u_ice, v_ice, siconc) -------------------------------
  * si3_part_tracker.py:372-374 reads one (Nj,Ni) slab of each per record.
  * `nslots` records are resident on the device; a slot is one contiguous slab

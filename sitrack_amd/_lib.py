@@ -32,6 +32,7 @@ _SIGNATURES = {
     "sitrk_set_stream": (_int, [_vp, _vp]),
     "sitrk_set_grid": (_int, [_vp, _int, _int] + [_vp] * 7),
     "sitrk_set_params": (_int, [_vp, _dbl, _int, _dbl]),
+    "sitrk_set_tuning": (_int, [_vp, C.c_char_p, _int]),
     "sitrk_alloc_records": (_int, [_vp, _int, _int]),
     "sitrk_push_record": (_int, [_vp, _int, _vp, _vp, _vp]),
     "sitrk_push_record_dev": (_int, [_vp, _int, _vp]),
@@ -160,6 +161,10 @@ class Context:
 
     def set_params(self, rdt=3600., uv_strategy=1, rmin_conc=0.1):
         self._chk(self._L.sitrk_set_params(self._h, float(rdt), int(uv_strategy), float(rmin_conc)))
+
+    def set_tuning(self, **knobs):
+        for k, v in knobs.items():
+            self._chk(self._L.sitrk_set_tuning(self._h, k.encode(), int(v)))
 
     def alloc_records(self, nslots, dtype=np.float32):
         dt = np.dtype(dtype)

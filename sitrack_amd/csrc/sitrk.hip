@@ -13,6 +13,7 @@
 #include "../../include/sitrk.h"
 #include "sitrk_internal.h"
 #include "sitrk_kernels.h"
+#include "sitrk_locate.h"
 
 using namespace sitrk;
 
@@ -181,6 +182,20 @@ SITRK_API int sitrk_set_params(sitrk_t *h, double rdt, int uv_strategy, double r
     return SITRK_OK;
 }
 
+SITRK_API int sitrk_set_tuning(sitrk_t *h, const char *knob, int value)
+{
+    NEED(h, "null handle");
+    NEED(knob, "sitrk_set_tuning: null knob");
+    int bit = 0;
+    if (!strcmp(knob, "xcd_remap")) bit = TUNE_XCD_REMAP;
+    else if (!strcmp(knob, "nt_state")) bit = TUNE_NT_STATE;
+    else if (!strcmp(knob, "compact")) bit = TUNE_COMPACT;
+    else if (!strcmp(knob, "locate_bruteforce")) bit = TUNE_LOCATE_BRUTEFORCE;
+    else return fail(h, SITRK_EINVAL, "sitrk_set_tuning: unknown knob '%s'", knob);
+    h->tune = value ? (h->tune | bit) : (h->tune & ~bit);
+    return SITRK_OK;
+}
+
 // --------------------------------------------------------------------------- records
 static inline size_t elem_size(int dtype) { return dtype == SITRK_F64 ? 8 : 4; }
 
@@ -328,13 +343,19 @@ template <typename FT>
 static void launch_step(sitrk_ctx *h, const StepArgs &a)
 {
     dim3 grid(nblocks(a.nP)), block(kBlock);
-    if (h->uv_strategy == 1) {
-        if (h->windowed) hipLaunchKernelGGL((advect_step_kernel<FT, 1, true>), grid, block, 0, h->stream, a);
-        else hipLaunchKernelGGL((advect_step_kernel<FT, 1, false>), grid, block, 0, h->stream, a);
-    } else {
-        if (h->windowed) hipLaunchKernelGGL((advect_step_kernel<FT, 0, true>), grid, block, 0, h->stream, a);
-        else hipLaunchKernelGGL((advect_step_kernel<FT, 0, false>), grid, block, 0, h->stream, a);
-    }
+#define SITRK_LAUNCH(KERNEL)                                                                              \
+    do {                                                                                                  \
+        if (h->uv_strategy == 1) {                                                                        \
+            if (h->windowed) hipLaunchKernelGGL((KERNEL<FT, 1, true>), grid, block, 0, h->stream, a);     \
+            else hipLaunchKernelGGL((KERNEL<FT, 1, false>), grid, block, 0, h->stream, a);                \
+        } else {                                                                                          \
+            if (h->windowed) hipLaunchKernelGGL((KERNEL<FT, 0, true>), grid, block, 0, h->stream, a);     \
+            else hipLaunchKernelGGL((KERNEL<FT, 0, false>), grid, block, 0, h->stream, a);                \
+        }                                                                                                 \
+    } while (0)
+    if (h->tune & TUNE_COMPACT) SITRK_LAUNCH(advect_step_compact_kernel);
+    else SITRK_LAUNCH(advect_step_kernel);
+#undef SITRK_LAUNCH
 }
 
 SITRK_API int sitrk_step(sitrk_t *h, int slot, int jrec)
@@ -352,7 +373,7 @@ SITRK_API int sitrk_step(sitrk_t *h, int slot, int jrec)
     const char *slab = (const char *)sitrk_record_ptr(h, slot);
     BuoyState &s = h->st[h->cur];
     StepArgs a;
-    a.nP = h->nP; a.Nj = h->Nj; a.Ni = h->Ni; a.jrec = jrec;
+    a.nP = h->nP; a.tune = h->tune; a.Nj = h->Nj; a.Ni = h->Ni; a.jrec = jrec;
     a.rdt = h->rdt; a.rmin_conc = h->rmin_conc;
     a.geo = h->geo; a.tmask = h->tmask;
     a.u = slab; a.v = slab + n * es; a.sic = slab + 2 * n * es;
@@ -529,9 +550,38 @@ SITRK_API int sitrk_seed_init(sitrk_t *h, int64_t nP, const double *latlon, cons
     if (resolkm) HIPCHK(hipMemcpyAsync(d_res, resolkm, n * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(d_sic, sic, n * 8, hipMemcpyHostToDevice, h->stream));
     // rFoundKM = 2.5 (tracking.py:5), max_itr = 10 (tracking.py:134)
-    hipLaunchKernelGGL(seed_init_bruteforce_kernel, dim3((unsigned)nP), dim3(kBlock), 0, h->stream, nP, h->Nj, h->Ni, d_ll, d_yx,
-                       d_lat, d_lon, resolkm ? d_res : nullptr, d_sic, h->tmask, h->geo, h->rmin_conc, 2.5, 10, d_ji, d_keep, d_why);
-    HIPCHK(hipGetLastError());
+    if (h->tune & TUNE_LOCATE_BRUTEFORCE) {
+        hipLaunchKernelGGL(seed_init_bruteforce_kernel, dim3((unsigned)nP), dim3(kBlock), 0, h->stream, nP, h->Nj, h->Ni, d_ll, d_yx,
+                           d_lat, d_lon, resolkm ? d_res : nullptr, d_sic, h->tmask, h->geo, h->rmin_conc, 2.5, 10, d_ji, d_keep, d_why);
+        HIPCHK(hipGetLastError());
+    } else {
+        // exact branch-and-bound over bounding spheres of the mesh (sitrk_locate.h)
+        const int nbj = (h->Nj + kLB - 1) / kLB, nbi = (h->Ni + kLB - 1) / kLB, sbf = 16;
+        const int nsj = (nbj + sbf - 1) / sbf, nsi = (nbi + sbf - 1) / sbf;
+        const size_t b_u = align256(n * 8), b_blk = align256((size_t)nbj * nbi * sizeof(Sphere)),
+                     b_sb = align256((size_t)nsj * nsi * sizeof(Sphere)), b_kb = align256((size_t)nP * 4), b_db = align256((size_t)nP * 8);
+        char *w = nullptr;
+        HIPCHK(hipMalloc((void **)&w, 3 * b_u + b_blk + b_sb + b_kb + b_db));
+        double *ux = (double *)w, *uy = (double *)(w + b_u), *uz = (double *)(w + 2 * b_u);
+        Sphere *blk = (Sphere *)(w + 3 * b_u), *sblk = (Sphere *)(w + 3 * b_u + b_blk);
+        uint32_t *kb = (uint32_t *)(w + 3 * b_u + b_blk + b_sb);
+        double *db = (double *)(w + 3 * b_u + b_blk + b_sb + b_kb);
+        hipLaunchKernelGGL(unitvec_kernel, dim3(nblocks((int64_t)n)), dim3(kBlock), 0, h->stream, n, d_lat, d_lon, ux, uy, uz);
+        hipLaunchKernelGGL(block_sphere_kernel, dim3((unsigned)(nbj * nbi)), dim3(kBlock), 0, h->stream, h->Nj, h->Ni, nbi, ux, uy, uz, blk);
+        hipLaunchKernelGGL(superblock_sphere_kernel, dim3((unsigned)(nsj * nsi)), dim3(kBlock), 0, h->stream, nbj, nbi, sbf, nsi, blk, sblk);
+        SearchArgs sa;
+        sa.nP = nP; sa.Nj = h->Nj; sa.Ni = h->Ni; sa.nbj = nbj; sa.nbi = nbi; sa.sbf = sbf; sa.nsj = nsj; sa.nsi = nsi;
+        sa.latlon = d_ll; sa.ux = ux; sa.uy = uy; sa.uz = uz; sa.blk = blk; sa.sblk = sblk; sa.latT = d_lat; sa.lonT = d_lon;
+        sa.kbest = kb; sa.dbest = db;
+        hipLaunchKernelGGL(seed_search_kernel, dim3(nblocks(nP, kBlock / 64)), dim3(kBlock), 0, h->stream, sa);
+        hipLaunchKernelGGL(seed_finish_kernel, dim3(nblocks(nP)), dim3(kBlock), 0, h->stream, nP, h->Nj, h->Ni, kb, db, d_yx,
+                           resolkm ? d_res : nullptr, d_sic, h->tmask, h->geo, h->rmin_conc, 2.5, 10, d_ji, d_keep, d_why);
+        hipError_t le = hipGetLastError();
+        hipError_t se = hipStreamSynchronize(h->stream);
+        (void)hipFree(w);
+        if (le != hipSuccess) return fail(h, SITRK_EHIP, "seed search launch -> %s", hipGetErrorString(le));
+        if (se != hipSuccess) return fail(h, SITRK_EHIP, "seed search -> %s", hipGetErrorString(se));
+    }
     HIPCHK(hipMemcpyAsync(jiT_out, d_ji, (size_t)nP * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(keep, d_keep, (size_t)nP, hipMemcpyDeviceToHost, h->stream));
     if (why) HIPCHK(hipMemcpyAsync(why, d_why, (size_t)nP, hipMemcpyDeviceToHost, h->stream));

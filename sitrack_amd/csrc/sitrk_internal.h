@@ -41,6 +41,7 @@ struct sitrk_ctx {
     double rdt = 3600.0;
     int uv_strategy = 1;
     double rmin_conc = 0.1;
+    int tune = 0;                       // TUNE_* bits (performance only)
 
     // records
     int nslots = 0, dtype = 0;

@@ -88,8 +88,40 @@ __device__ __forceinline__ void new_host_cell(pt P1, pt P2, pt bl, pt br, pt ur,
     di = (knhc == 4 || knhc == 5 || knhc == 8) ? -1 : ((knhc == 2 || knhc == 6 || knhc == 7) ? 1 : 0);
 }
 
+// performance knobs (never change results)
+enum : int {
+    TUNE_XCD_REMAP = 1,    // give each XCD a contiguous chunk of the sorted buoys (neighbour rows hit the same L2)
+    TUNE_NT_STATE = 2,     // stream pos/cell with non-temporal loads/stores: they are touched once per step
+    TUNE_COMPACT = 4,      // workgroup compaction of the crossing path (advect_step_compact_kernel)
+    TUNE_LOCATE_BRUTEFORCE = 8,   // SeedInit: whole-grid Haversine scan per seed (the reference's algorithm) instead of the sphere search
+};
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ pt load_pt_nt(const pt *p)
+{
+    v2d t = __builtin_nontemporal_load((const v2d *)p);
+    return make_pt(t.x, t.y);
+}
+__device__ __forceinline__ void store_pt_nt(pt *p, pt v)
+{
+    v2d t;
+    t.x = v.y; t.y = v.x;
+    __builtin_nontemporal_store(t, (v2d *)p);
+}
+
+// Workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MiB L2).  Map the hardware block id
+// to a logical one so that XCD x walks the contiguous chunk x of the cell-sorted buoys: the row j-1 records a
+// workgroup needs were fetched a few workgroups earlier BY THE SAME XCD.  Bijective for any grid size.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg)
+{
+    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u, k = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 struct StepArgs {
     int64_t nP;
+    int tune;
     int Nj, Ni;
     int jrec;
     double rdt, rmin_conc;
@@ -110,9 +142,11 @@ struct StepArgs {
 template <typename FT, int UVS, bool WINDOW>
 __global__ __launch_bounds__(kBlock) void advect_step_kernel(StepArgs a)
 {
-    int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const unsigned blk = (a.tune & TUNE_XCD_REMAP) ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    int64_t p = (int64_t)blk * kBlock + threadIdx.x;
     if (p >= a.nP) return;
-    int32_t c = a.cell[p];
+    const bool nt = (a.tune & TUNE_NT_STATE) != 0;
+    int32_t c = nt ? __builtin_nontemporal_load(&a.cell[p]) : a.cell[p];
     if (c < 0) return;                                   // iAlive != 1
     if (WINDOW) {
         if (a.jrec < a.first[p] || a.jrec > a.last[p]) return;
@@ -123,7 +157,7 @@ __global__ __launch_bounds__(kBlock) void advect_step_kernel(StepArgs a)
     const FT *__restrict__ u = (const FT *)a.u;
     const FT *__restrict__ v = (const FT *)a.v;
 
-    const pt P = a.pos[p];                               // (ry, rx)
+    const pt P = nt ? load_pt_nt(&a.pos[p]) : a.pos[p];  // (ry, rx)
     // cell (jT,iT): F = upper-right vertex, U = right U-point, V = upper V-point
     const CellGeo g11 = a.geo[k];
     const pt F10 = a.geo[k - 1].f;                       // F[jT  ,iT-1]  upper-left
@@ -151,7 +185,8 @@ __global__ __launch_bounds__(kBlock) void advect_step_kernel(StepArgs a)
     pt Pn;
     Pn.x = P.x + dx / 1000.;
     Pn.y = P.y + dy / 1000.;
-    a.pos[p] = Pn;                                       // written before the kill test (:459-460)
+    if (nt) store_pt_nt(&a.pos[p], Pn);                  // written before the kill test (:459-460)
+    else a.pos[p] = Pn;
 
     // still inside the host cell? (:466) quad = [bl, br, ur, ul]
     if (!inside_quad(Pn.y, Pn.x, F00, F01, g11.f, F10)) {
@@ -164,6 +199,120 @@ __global__ __launch_bounds__(kBlock) void advect_step_kernel(StepArgs a)
             a.kill_rec[p] = a.jrec;
         }
         a.cell[p] = cn;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Same record step with WORKGROUP COMPACTION OF THE CROSSING PATH.
+//
+// Only 3-16 % of buoys leave their cell in a step, but almost every wavefront has at least
+// one that does, so in the one-pass kernel every wave pays the whole CrossedEdge /
+// NewHostCell / Survive instruction stream (~45 % of its fp64 work; fp64 issues at 16
+// lanes/clk, 4 cycles per wave64 instruction, and this kernel is as VALU-heavy as it is
+// HBM-heavy) for a handful of active lanes.  Here the lanes that crossed append
+// (buoy, old position, new position, cell) to an LDS queue (one LDS atomic per wave, ballot +
+// popcount for the slot), and after one barrier the queue is drained by densely packed lanes:
+// typically ONE wave of the four does the crossing work of the whole workgroup.
+// Buoys are independent, so the queue order does not matter: results are bit-identical.
+// ---------------------------------------------------------------------------
+struct CrossItem {
+    pt P, Pn;          // position before / after the Euler step
+    int32_t cell;      // packed host cell before the move
+    int32_t slot;      // index within the workgroup's 256 buoys
+};
+
+template <typename FT, int UVS, bool WINDOW>
+__global__ __launch_bounds__(kBlock) void advect_step_compact_kernel(StepArgs a)
+{
+    __shared__ CrossItem queue[kBlock];
+    __shared__ int qcount;
+    if (threadIdx.x == 0) qcount = 0;
+    __syncthreads();
+
+    const unsigned blk = (a.tune & TUNE_XCD_REMAP) ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int64_t p0 = (int64_t)blk * kBlock;
+    const int64_t p = p0 + threadIdx.x;
+    const bool nt = (a.tune & TUNE_NT_STATE) != 0;
+    const int Ni = a.Ni, Nj = a.Nj;
+
+    bool active = p < a.nP;
+    int32_t c = 0;
+    if (active) {
+        c = nt ? __builtin_nontemporal_load(&a.cell[p]) : a.cell[p];
+        active = c >= 0;                                   // iAlive == 1
+    }
+    if (WINDOW) {
+        if (active) active = (a.jrec >= a.first[p]) && (a.jrec <= a.last[p]);
+    }
+
+    bool crossed = false;
+    pt P = make_pt(0., 0.), Pn = P;
+    if (active) {
+        const int jT = cell_j(c), iT = cell_i(c);
+        const size_t k = (size_t)jT * Ni + iT;
+        const FT *__restrict__ u = (const FT *)a.u;
+        const FT *__restrict__ v = (const FT *)a.v;
+        P = nt ? load_pt_nt(&a.pos[p]) : a.pos[p];
+        const CellGeo g11 = a.geo[k];
+        const pt F10 = a.geo[k - 1].f;
+        const pt F01 = a.geo[k - Ni].f;
+        const pt F00 = a.geo[k - Ni - 1].f;
+        double zU, zV;
+        if (UVS == 0) {                                      // :423-425
+            zU = 0.5 * ((double)u[k] + (double)u[k - 1]);
+            zV = 0.5 * ((double)v[k] + (double)v[k - Ni]);
+        } else {                                             // :427-441
+            const pt U10 = a.geo[k - 1].u;
+            const pt V01 = a.geo[k - Ni].v;
+            const double u1 = (double)u[k], u0 = (double)u[k - 1];
+            const double v1 = (double)v[k], v0 = (double)v[k - Ni];
+            const bool llum1 = intersect2seg(P, g11.f, V01, g11.v);
+            const bool llvm1 = intersect2seg(P, g11.f, U10, g11.u);
+            zU = llum1 ? u0 : u1;
+            zV = llvm1 ? v0 : v1;
+        }
+        const double dx = zU * a.rdt;                        // :452-458
+        const double dy = zV * a.rdt;
+        Pn.x = P.x + dx / 1000.;
+        Pn.y = P.y + dy / 1000.;
+        if (nt) store_pt_nt(&a.pos[p], Pn);                  // :459-460
+        else a.pos[p] = Pn;
+        crossed = !inside_quad(Pn.y, Pn.x, F00, F01, g11.f, F10);   // :466
+    }
+
+    // ---- enqueue the lanes that left their cell
+    const unsigned long long m = __ballot(crossed);
+    if (m) {
+        const int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&qcount, __popcll(m));
+        base = __shfl(base, 0);
+        if (crossed) {
+            const int at = base + __popcll(m & ((1ull << lane) - 1ull));
+            CrossItem it;
+            it.P = P; it.Pn = Pn; it.cell = c; it.slot = (int32_t)threadIdx.x;
+            queue[at] = it;
+        }
+    }
+    __syncthreads();
+
+    // ---- drain: CrossedEdge / NewHostCell / UpdtInd4NewCell / Survive (:474-484) on dense lanes
+    const int n = qcount;
+    for (int t = threadIdx.x; t < n; t += kBlock) {
+        const CrossItem it = queue[t];
+        const int jT = cell_j(it.cell), iT = cell_i(it.cell);
+        const size_t k = (size_t)jT * Ni + iT;
+        const pt F11 = a.geo[k].f, F10 = a.geo[k - 1].f, F01 = a.geo[k - Ni].f, F00 = a.geo[k - Ni - 1].f;
+        int dj, di;
+        new_host_cell(it.P, it.Pn, F00, F01, F11, F10, jT, iT, Nj, Ni, a.geo, dj, di);
+        const int jN = jT + dj, iN = iT + di;
+        int32_t cn = pack_cell(jN, iN);
+        const int64_t q = p0 + it.slot;
+        if (survive_kill<FT>(jN, iN, Nj, Ni, a.tmask, (const FT *)a.sic, a.rmin_conc)) {
+            cn |= SITRK_DEAD_BIT;
+            a.kill_rec[q] = a.jrec;
+        }
+        a.cell[q] = cn;
     }
 }
 

@@ -122,6 +122,29 @@ def test_run_many_steps_equals_stepping(ctx):
         assert np.array_equal(res[0][key], res[1][key])
 
 
+def test_tuning_knobs_do_not_change_results():
+    grid = syn.make_grid(128, 160, dkm=4.0, warp=1.0)
+    u, v, sic = syn.make_fields(grid, K=3, seed=8, umax=0.7, drift=0.2, ripple=0.1)
+    _, yx = syn.make_buoys(grid, 30011, seed=21, frac=0.7)
+    res = []
+    for knobs in ({}, {"xcd_remap": 1}, {"nt_state": 1}, {"xcd_remap": 1, "nt_state": 1}, {"compact": 1},
+                  {"compact": 1, "nt_state": 1, "xcd_remap": 1}):
+        trk = make_tracker(grid, grid["tmask"], 3)
+        found, ji, _ = sit.FindContainingCell(yx, syn.nearest_t_plane(grid, yx), ctx=trk.ctx)
+        trk.set_buoys(yx[found], ji[found])
+        trk.ctx.set_tuning(**knobs)
+        for k in range(3):
+            trk.load_record(k, u[k], v[k], sic[k])
+        trk.ctx.run(0, 0, 25)
+        res.append(trk.state())
+        trk.close()
+    for r in res[1:]:
+        for key in ("yx", "vJIt", "iAlive", "kill_rec"):
+            assert np.array_equal(r[key], res[0][key])
+    with pytest.raises(sit.SitrkError):
+        sit.Context(0).set_tuning(bogus=1)
+
+
 def test_find_cells_matches_golden(golden, ctx):
     g = golden("g5_seedinit.npz")
     Nj, Ni = g["latT"].shape
@@ -144,6 +167,67 @@ def test_seed_init_matches_golden(golden):
     assert np.array_equal(ojiT, g["ojiT"])
     assert np.array_equal(overt, g["overt"])
     assert np.array_equal(oSG, g["oSG"]) and np.array_equal(oSC, g["oSC"])
+
+
+def test_seed_init_bruteforce_mode_matches_golden(golden, ctx):
+    """The whole-grid scan (the reference's own algorithm) stays available behind a knob and agrees too."""
+    g = golden("g5_seedinit.npz")
+    ctx.set_grid(g["Yf"], g["Xf"], g["Yf"], g["Xf"], g["Yf"], g["Xf"], g["tmask"])
+    ctx.set_tuning(locate_bruteforce=1)
+    try:
+        out = sit.SeedInit(g["ids"], g["pSG"], g["pSC"], g["latT"], g["lonT"], g["Yf"], g["Xf"], g["resol"], g["tmask"],
+                           xIceConc=g["sic"], ctx=ctx)
+    finally:
+        ctx.set_tuning(locate_bruteforce=0)
+    assert out[0] == int(g["nPn"]) and np.array_equal(out[6], g["okeep"]) and np.array_equal(out[4], g["ojiT"])
+
+
+@pytest.mark.parametrize("yc,xc", [(-300., 200.), (0., 0.), (-2500., 1800.)])
+def test_seed_search_equals_whole_grid_scan(ctx, yc, xc):
+    """Bounding-sphere search == exhaustive Haversine argmin, incl. seeds exactly on T- and F-points
+    (exact ties between T-points), seeds far outside the mesh, and a mesh that contains the pole."""
+    Nj, Ni, dkm = 150, 170, 9.0
+    grid = syn.make_grid(Nj, Ni, dkm=dkm, warp=1.0)
+    for k in ("Yt", "Yu", "Yv", "Yf"):
+        grid[k] = grid[k] + yc
+    for k in ("Xt", "Xu", "Xv", "Xf"):
+        grid[k] = grid[k] + xc
+    llT = orc.CartNPSkm2Geo1D(np.stack([grid["Yt"].ravel(), grid["Xt"].ravel()], axis=1))
+    latT = np.ascontiguousarray(llT[:, 0].reshape(Nj, Ni))
+    lonT = np.ascontiguousarray(np.mod(llT[:, 1], 360.).reshape(Nj, Ni))
+    rng = np.random.default_rng(17)
+    n_r = 6000
+    yx = np.stack([rng.uniform(grid["Yt"].min() - 60, grid["Yt"].max() + 60, n_r),
+                   rng.uniform(grid["Xt"].min() - 60, grid["Xt"].max() + 60, n_r)], axis=1)
+    jj, ii = rng.integers(0, Nj, 1500), rng.integers(0, Ni, 1500)
+    onT = np.stack([grid["Yt"][jj, ii], grid["Xt"][jj, ii]], axis=1)
+    onF = np.stack([grid["Yf"][jj, ii], grid["Xf"][jj, ii]], axis=1)
+    far = np.array([[grid["Yt"].min() - 900., xc], [yc, grid["Xt"].max() + 1500.], [yc + 4000., xc - 4000.]])
+    yx = np.concatenate([yx, onT, onF, far])
+    ll = orc.CartNPSkm2Geo1D(yx)
+    ll[:, 1] = np.mod(ll[:, 1], 360.)
+    # seeds on T-points get the grid's own lat/lon bit for bit (distance exactly 0)
+    ll[n_r:n_r + 1500, 0] = latT[jj, ii]
+    ll[n_r:n_r + 1500, 1] = lonT[jj, ii]
+    tmask = grid["tmask"].copy(); tmask[60:70, 80:95] = 0
+    sic = np.ones((Nj, Ni)); sic[20:40, 20:50] = 0.05
+    ctx.set_grid(grid["Yf"], grid["Xf"], grid["Yf"], grid["Xf"], grid["Yf"], grid["Xf"], tmask)
+    res = {}
+    for mode in (0, 1):
+        ctx.set_tuning(locate_bruteforce=mode)
+        res[mode] = ctx.seed_init(ll, yx, latT, lonT, grid["resol"], sic)
+    ctx.set_tuning(locate_bruteforce=0)
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+    assert 0 < res[0][1].sum() < len(yx)
+    # and the oracle agrees on a subsample (nearest T-point, Survive, containing cell)
+    sel = np.r_[0:200, n_r:n_r + 60, n_r + 1500:n_r + 1560, len(yx) - 3:len(yx)]
+    o = orc.SeedInit(np.arange(len(sel)), ll[sel], yx[sel], latT, lonT, grid["Yf"], grid["Xf"], grid["resol"], tmask, sic,
+                     return_why=True)
+    keep_o = np.zeros(len(sel), dtype=np.int8); keep_o[o[6]] = 1
+    assert np.array_equal(keep_o, res[0][1][sel])
+    assert np.array_equal(o[7], res[0][2][sel])
+    assert np.array_equal(o[4], res[0][0][sel][keep_o == 1])
 
 
 def test_projection(golden, ctx):

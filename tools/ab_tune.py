@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Interleaved A/B of libsitrk performance knobs on one GPU, one process (C3 workload).
+
+    python tools/ab_tune.py [--config c3] [--steps 200] [--rounds 5]
+Prints median / min ms per step for every knob combination; results must not depend on knobs
+(checked on the final state against the first variant)."""
+import argparse
+import itertools
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import sitrack_amd as sit                      # noqa: E402
+from sitrack_amd import synthetic as syn       # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--grid", type=int, default=4096)
+    ap.add_argument("--buoys", type=int, default=10_000_000)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--knobs", default="xcd_remap,nt_state")
+    a = ap.parse_args()
+    N, nP, K = a.grid, a.buoys, 8
+    grid = syn.make_grid(N, N, dkm=4.0, warp=0.0)
+    _, yx = syn.make_buoys(grid, nP, seed=1234, frac=0.6)
+    ji = syn.regular_host_cell(grid, yx).astype(np.int32)
+    u, v, sic = syn.make_fields(grid, K=K, seed=2024, umax=0.3, drift=0.05)
+    ctx = sit.Context(0)
+    ctx.set_grid(grid["Yf"], grid["Xf"], grid["Yu"], grid["Xu"], grid["Yv"], grid["Xv"], grid["tmask"])
+    ctx.alloc_records(K, np.float32)
+    for k in range(K):
+        ctx.push_record(k, u[k], v[k], sic[k])
+    knobs = [k for k in a.knobs.split(",") if k]
+    variants = [dict(zip(knobs, bits)) for bits in itertools.product((0, 1), repeat=len(knobs))]
+    times = {i: [] for i in range(len(variants))}
+    ref = None
+    for rnd in range(a.rounds):
+        for i, var in enumerate(variants):
+            ctx.set_buoys(yx, ji)                  # same start every time
+            ctx.set_tuning(**var)
+            ctx.run(0, 0, 10)
+            ctx.sync()
+            ctx.timer_start()
+            ctx.run(10 % K, 10, a.steps)
+            ms = ctx.timer_stop()
+            times[i].append(ms / a.steps)
+            if rnd == 0:
+                st = ctx.fetch(("yx", "jiT"))
+                if ref is None:
+                    ref = st
+                else:
+                    assert np.array_equal(st["yx"], ref["yx"]) and np.array_equal(st["jiT"], ref["jiT"]), var
+    for i, var in enumerate(variants):
+        t = np.array(times[i])
+        print("%-40s median %.4f ms  min %.4f ms  (%.3e p-steps/s)" % (var, np.median(t), t.min(), nP / np.median(t) * 1e3))
+
+
+if __name__ == "__main__":
+    main()
