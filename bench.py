@@ -186,6 +186,7 @@ def main():
                 if sidx + 1 < s0 + n:
                     deliver(sidx + 1)
                 comp.wait_event(ready[sidx % 2])
+                ctx.commit_record(sidx % 2)          # the slab was rewritten in place: refresh its Survive mask
                 ctx.step(sidx % 2, sidx)
                 free[sidx % 2].record(comp)
 

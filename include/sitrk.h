@@ -76,9 +76,9 @@ int sitrk_set_params(sitrk_t *h, double rdt, int uv_strategy, double rmin_conc);
 
 /* performance knobs; they never change results.  "xcd_remap" (0/1): each XCD walks a
  * contiguous chunk of the cell-sorted buoys; "nt_state" (0/1): non-temporal loads/stores for
- * the once-per-step position/cell streams; "compact" (0/1): workgroup compaction of the
- * cell-crossing path; "locate_bruteforce" (0/1): SeedInit scans the whole grid per seed like
- * the reference instead of the bounding-sphere search. */
+ * the once-per-step position/cell streams; "sort_tile" (tile_j*256 + tile_i, 0 = row-major):
+ * order of the cell sort, tile-major tiles of tile_j x tile_i cells; "locate_bruteforce" (0/1):
+ * SeedInit scans the whole grid per seed like the reference instead of the bounding-sphere search. */
 int sitrk_set_tuning(sitrk_t *h, const char *knob, int value);
 
 /* ---- model records (u_ice, v_ice, siconc) -------------------------------
@@ -89,6 +89,11 @@ int   sitrk_alloc_records(sitrk_t *h, int nslots, int dtype);
 int   sitrk_push_record(sitrk_t *h, int slot, const void *u, const void *v, const void *sic);   /* host pointers   */
 int   sitrk_push_record_dev(sitrk_t *h, int slot, const void *slab_dev);                        /* device pointer: [u|v|sic] */
 void *sitrk_record_ptr(sitrk_t *h, int slot);   /* device address of a slot's slab (broadcast target); NULL on error */
+/* A slot whose slab was (re)written in place through sitrk_record_ptr must be committed before it is
+ * stepped with: this derives the record's Survive mask (sitrack/tracking.py:62-93 evaluated once per cell:
+ * rim, 5-point tmask sum, 5-point siconc mean < rmin_conc) on the library's stream.  push_record* commit
+ * by themselves; a slot handed out by sitrk_record_ptr and never committed is committed by the next step. */
+int   sitrk_commit_record(sitrk_t *h, int slot);
 
 /* ---- buoys ---------------------------------------------------------------
  * State of si3_part_tracker.py:324-330 reduced to what the loop reads:

@@ -37,6 +37,7 @@ _SIGNATURES = {
     "sitrk_push_record": (_int, [_vp, _int, _vp, _vp, _vp]),
     "sitrk_push_record_dev": (_int, [_vp, _int, _vp]),
     "sitrk_record_ptr": (_vp, [_vp, _int]),
+    "sitrk_commit_record": (_int, [_vp, _int]),
     "sitrk_set_buoys": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "sitrk_sort_buoys": (_int, [_vp]),
     "sitrk_set_resort": (_int, [_vp, _int]),
@@ -190,6 +191,9 @@ class Context:
         if not p:
             raise SitrkError("sitrk_record_ptr: bad slot %d" % slot)
         return p
+
+    def commit_record(self, slot):
+        self._chk(self._L.sitrk_commit_record(self._h, int(slot)))
 
     @property
     def slab_elems(self):

@@ -119,7 +119,7 @@ SITRK_API int sitrk_destroy(sitrk_t *h)
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     free_buoys(h);
-    dev_free(h->geo); dev_free(h->tmask); dev_free(h->slabs); dev_free(h->scratch); dev_free(h->counter);
+    dev_free(h->geo); dev_free(h->tmask); dev_free(h->slabs); dev_free(h->kill); dev_free(h->scratch); dev_free(h->counter);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -152,8 +152,8 @@ SITRK_API int sitrk_set_grid(sitrk_t *h, int Nj, int Ni, const double *Yf, const
         return fail(h, SITRK_EINVAL, "sitrk_set_grid: grid %dx%d outside 4..32767 x 4..65535", Nj, Ni);
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
-    dev_free(h->geo); dev_free(h->tmask); dev_free(h->slabs);
-    h->geo = nullptr; h->tmask = nullptr; h->slabs = nullptr; h->nslots = 0;
+    dev_free(h->geo); dev_free(h->tmask); dev_free(h->slabs); dev_free(h->kill);
+    h->geo = nullptr; h->tmask = nullptr; h->slabs = nullptr; h->kill = nullptr; h->nslots = 0;
     free_buoys(h);
     const size_t n = (size_t)Nj * Ni;
     HIPCHK(dev_alloc(&h->geo, n));
@@ -178,6 +178,7 @@ SITRK_API int sitrk_set_params(sitrk_t *h, double rdt, int uv_strategy, double r
     NEED(h, "null handle");
     NEED(uv_strategy == 0 || uv_strategy == 1, "sitrk_set_params: uv_strategy must be 0 (cell mean) or 1 (nearest U/V point)");
     NEED(rdt > 0.0, "sitrk_set_params: rdt must be > 0");
+    if (rmin_conc != h->rmin_conc) memset(h->slot_dirty, 1, sizeof(h->slot_dirty));     // masks depend on it
     h->rdt = rdt; h->uv_strategy = uv_strategy; h->rmin_conc = rmin_conc;
     return SITRK_OK;
 }
@@ -189,8 +190,17 @@ SITRK_API int sitrk_set_tuning(sitrk_t *h, const char *knob, int value)
     int bit = 0;
     if (!strcmp(knob, "xcd_remap")) bit = TUNE_XCD_REMAP;
     else if (!strcmp(knob, "nt_state")) bit = TUNE_NT_STATE;
-    else if (!strcmp(knob, "compact")) bit = TUNE_COMPACT;
+    else if (!strcmp(knob, "sort_tile")) {           // value = tile_j * 256 + tile_i, 0 = row-major
+        const int tj = value >> 8, ti = value & 255;
+        if (value != 0 && (tj < 1 || ti < 1)) return fail(h, SITRK_EINVAL, "sitrk_set_tuning: sort_tile = tile_j*256 + tile_i");
+        h->tile_j = tj; h->tile_i = ti;
+        return SITRK_OK;
+    }
     else if (!strcmp(knob, "locate_bruteforce")) bit = TUNE_LOCATE_BRUTEFORCE;
+#ifdef SITRK_DIAG
+    else if (!strcmp(knob, "diag_memonly")) bit = TUNE_DIAG_MEMONLY;
+    else if (!strcmp(knob, "diag_nocross")) bit = TUNE_DIAG_NOCROSS;
+#endif
     else return fail(h, SITRK_EINVAL, "sitrk_set_tuning: unknown knob '%s'", knob);
     h->tune = value ? (h->tune | bit) : (h->tune & ~bit);
     return SITRK_OK;
@@ -207,18 +217,49 @@ SITRK_API int sitrk_alloc_records(sitrk_t *h, int nslots, int dtype)
     NEED(dtype == SITRK_F32 || dtype == SITRK_F64, "sitrk_alloc_records: dtype must be SITRK_F32 or SITRK_F64");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
-    dev_free(h->slabs);
-    h->slabs = nullptr; h->nslots = 0;
+    dev_free(h->slabs); dev_free(h->kill);
+    h->slabs = nullptr; h->kill = nullptr; h->nslots = 0;
     h->slab_bytes = 3 * (size_t)h->Nj * h->Ni * elem_size(dtype);
     HIPCHK(hipMalloc(&h->slabs, h->slab_bytes * nslots));
+    HIPCHK(hipMalloc((void **)&h->kill, (size_t)h->Nj * h->Ni * nslots));
     h->nslots = nslots; h->dtype = dtype;
+    memset(h->slot_dirty, 1, sizeof(h->slot_dirty));
     return SITRK_OK;
 }
+
+static inline char *slab_of(sitrk_ctx *h, int slot) { return (char *)h->slabs + (size_t)slot * h->slab_bytes; }
 
 SITRK_API void *sitrk_record_ptr(sitrk_t *h, int slot)
 {
     if (!h || !h->slabs || slot < 0 || slot >= h->nslots) return nullptr;
-    return (char *)h->slabs + (size_t)slot * h->slab_bytes;
+    h->slot_dirty[slot] = 1;            // the caller is about to write the slab
+    return slab_of(h, slot);
+}
+
+// derive the slot's Survive mask from its siconc slab (queued on the compute stream)
+static int derive_mask(sitrk_ctx *h, int slot)
+{
+    const size_t n = (size_t)h->Nj * h->Ni, es = elem_size(h->dtype);
+    const char *sic = slab_of(h, slot) + 2 * n * es;
+    int8_t *kill = h->kill + (size_t)slot * n;
+    if (h->dtype == SITRK_F64)
+        hipLaunchKernelGGL((survive_mask_kernel<double>), dim3(nblocks((int64_t)n)), dim3(kBlock), 0, h->stream, h->Nj, h->Ni, h->tmask,
+                           (const double *)sic, h->rmin_conc, kill);
+    else
+        hipLaunchKernelGGL((survive_mask_kernel<float>), dim3(nblocks((int64_t)n)), dim3(kBlock), 0, h->stream, h->Nj, h->Ni, h->tmask,
+                           (const float *)sic, h->rmin_conc, kill);
+    HIPCHK(hipGetLastError());
+    h->slot_dirty[slot] = 0;
+    return SITRK_OK;
+}
+
+SITRK_API int sitrk_commit_record(sitrk_t *h, int slot)
+{
+    NEED(h, "null handle");
+    NEED(h->slabs, "sitrk_commit_record: call sitrk_alloc_records first");
+    NEED(slot >= 0 && slot < h->nslots, "sitrk_commit_record: slot out of range");
+    HIPCHK(hipSetDevice(h->device));
+    return derive_mask(h, slot);
 }
 
 SITRK_API int sitrk_push_record(sitrk_t *h, int slot, const void *u, const void *v, const void *sic)
@@ -229,11 +270,11 @@ SITRK_API int sitrk_push_record(sitrk_t *h, int slot, const void *u, const void 
     NEED(u && v && sic, "sitrk_push_record: null field");
     HIPCHK(hipSetDevice(h->device));
     const size_t nb = h->slab_bytes / 3;
-    char *d = (char *)sitrk_record_ptr(h, slot);
+    char *d = slab_of(h, slot);
     HIPCHK(hipMemcpyAsync(d, u, nb, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(d + nb, v, nb, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(d + 2 * nb, sic, nb, hipMemcpyHostToDevice, h->stream));
-    return SITRK_OK;
+    return derive_mask(h, slot);
 }
 
 SITRK_API int sitrk_push_record_dev(sitrk_t *h, int slot, const void *slab_dev)
@@ -243,9 +284,9 @@ SITRK_API int sitrk_push_record_dev(sitrk_t *h, int slot, const void *slab_dev)
     NEED(slot >= 0 && slot < h->nslots, "sitrk_push_record_dev: slot out of range");
     NEED(slab_dev, "sitrk_push_record_dev: null slab");
     HIPCHK(hipSetDevice(h->device));
-    void *d = sitrk_record_ptr(h, slot);
+    void *d = slab_of(h, slot);
     if (d != slab_dev) HIPCHK(hipMemcpyAsync(d, slab_dev, h->slab_bytes, hipMemcpyDeviceToDevice, h->stream));
-    return SITRK_OK;
+    return derive_mask(h, slot);
 }
 
 // --------------------------------------------------------------------------- buoys
@@ -316,10 +357,17 @@ SITRK_API int sitrk_sort_buoys(sitrk_t *h)
     if (nP <= 1) return SITRK_OK;
     HIPCHK(hipSetDevice(h->device));
     BuoyState &in = h->st[h->cur], &out = h->st[h->cur ^ 1];
-    const uint32_t dead_key = (uint32_t)h->Nj * (uint32_t)h->Ni;
+    // keys are < (#tiles) * tile cells (row-major: Nj*Ni); the dead key sits just above
+    uint32_t dead_key = (uint32_t)h->Nj * (uint32_t)h->Ni;
+    if (h->tile_j) {
+        const uint64_t ntj = ((uint64_t)h->Nj + h->tile_j - 1) / h->tile_j, nti = ((uint64_t)h->Ni + h->tile_i - 1) / h->tile_i;
+        const uint64_t lim = ntj * nti * (uint64_t)(h->tile_j * h->tile_i);
+        if (lim >= 0xffffffffull) return fail(h, SITRK_EINVAL, "sitrk_sort_buoys: tile-major key does not fit 32 bits");
+        dead_key = (uint32_t)lim;
+    }
     unsigned end_bit = 1;
     while (end_bit < 32 && (dead_key >> end_bit)) end_bit++;
-    hipLaunchKernelGGL(make_keys_kernel, dim3(nblocks(nP)), dim3(kBlock), 0, h->stream, nP, h->Ni, dead_key, in.cell, h->keys[0], h->vals[0]);
+    hipLaunchKernelGGL(make_keys_kernel, dim3(nblocks(nP)), dim3(kBlock), 0, h->stream, nP, h->Ni, h->tile_j, h->tile_i, dead_key, in.cell, h->keys[0], h->vals[0]);
     HIPCHK(hipGetLastError());
     size_t need = 0;
     HIPCHK(sort_pairs_u32(nullptr, &need, h->keys[0], h->keys[1], h->vals[0], h->vals[1], (size_t)nP, end_bit, h->stream));
@@ -353,8 +401,11 @@ static void launch_step(sitrk_ctx *h, const StepArgs &a)
             else hipLaunchKernelGGL((KERNEL<FT, 0, false>), grid, block, 0, h->stream, a);                \
         }                                                                                                 \
     } while (0)
-    if (h->tune & TUNE_COMPACT) SITRK_LAUNCH(advect_step_compact_kernel);
-    else SITRK_LAUNCH(advect_step_kernel);
+#ifdef SITRK_DIAG
+    if (h->tune & TUNE_DIAG_MEMONLY) { hipLaunchKernelGGL((advect_memonly_kernel<FT>), grid, block, 0, h->stream, a); return; }
+    if (h->tune & TUNE_DIAG_NOCROSS) { hipLaunchKernelGGL((advect_nocross_kernel<FT>), grid, block, 0, h->stream, a); return; }
+#endif
+    SITRK_LAUNCH(advect_step_kernel);
 #undef SITRK_LAUNCH
 }
 
@@ -369,14 +420,18 @@ SITRK_API int sitrk_step(sitrk_t *h, int slot, int jrec)
         int rc = sitrk_sort_buoys(h);
         if (rc) return rc;
     }
+    if (h->slot_dirty[slot]) {            // slab written through sitrk_record_ptr and not committed yet
+        int rc = derive_mask(h, slot);
+        if (rc) return rc;
+    }
     const size_t n = (size_t)h->Nj * h->Ni, es = elem_size(h->dtype);
-    const char *slab = (const char *)sitrk_record_ptr(h, slot);
+    const char *slab = slab_of(h, slot);
     BuoyState &s = h->st[h->cur];
     StepArgs a;
     a.nP = h->nP; a.tune = h->tune; a.Nj = h->Nj; a.Ni = h->Ni; a.jrec = jrec;
     a.rdt = h->rdt; a.rmin_conc = h->rmin_conc;
-    a.geo = h->geo; a.tmask = h->tmask;
-    a.u = slab; a.v = slab + n * es; a.sic = slab + 2 * n * es;
+    a.geo = h->geo; a.kill = h->kill + (size_t)slot * n;
+    a.u = slab; a.v = slab + n * es;
     a.pos = s.pos; a.cell = s.cell; a.kill_rec = s.kill_rec; a.first = s.first; a.last = s.last;
     if (h->dtype == SITRK_F64) launch_step<double>(h, a);
     else launch_step<float>(h, a);

@@ -75,4 +75,13 @@ __host__ __device__ __forceinline__ int cell_j(int32_t c) { return (c >> 16) & 0
 __host__ __device__ __forceinline__ int cell_i(int32_t c) { return c & 0xffff; }
 #define SITRK_DEAD_BIT ((int32_t)0x80000000)
 
+// performance knobs (never change results)
+enum : int {
+    TUNE_XCD_REMAP = 1,            // give each XCD a contiguous chunk of the sorted buoys
+    TUNE_NT_STATE = 2,             // non-temporal loads/stores for the once-per-step pos/cell streams
+    TUNE_LOCATE_BRUTEFORCE = 8,    // SeedInit: whole-grid Haversine scan per seed (the reference's algorithm)
+    TUNE_DIAG_MEMONLY = 16,        // ablation kernels, diagnostic builds only (make DIAG=1)
+    TUNE_DIAG_NOCROSS = 32,
+};
+
 }  // namespace sitrk

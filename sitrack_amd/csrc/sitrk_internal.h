@@ -41,12 +41,17 @@ struct sitrk_ctx {
     double rdt = 3600.0;
     int uv_strategy = 1;
     double rmin_conc = 0.1;
-    int tune = 0;                       // TUNE_* bits (performance only)
+    // performance knobs and their measured defaults (tools/ab_tune.py on MI355X, C3):
+    // non-temporal state streams -2 %, tile-major 8x16 cell order -8 %, XCD-chunked block order +5 % (off)
+    int tune = sitrk::TUNE_NT_STATE;    // TUNE_* bits
+    int tile_j = 8, tile_i = 16;        // sort order: 0 = row-major cells, else tile-major tiles of tile_j x tile_i cells
 
     // records
     int nslots = 0, dtype = 0;
     size_t slab_bytes = 0;
     void *slabs = nullptr;              // nslots * [u|v|sic]
+    int8_t *kill = nullptr;             // nslots * (Nj*Ni) Survive masks derived from (tmask, sic, rmin_conc)
+    unsigned char slot_dirty[4096] = {0};   // slab (re)written since its mask was derived
 
     // buoys
     int64_t nP = 0;

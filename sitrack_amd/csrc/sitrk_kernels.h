@@ -51,50 +51,79 @@ __device__ __forceinline__ bool survive_kill(int jT, int iT, int Nj, int Ni, con
     return zic < rmin_conc;
 }
 
+// ---------------------------------------------------------------------------
+// Per-record Survive mask.  `Survive` (tracking.py:62-93) depends only on the cell and on the
+// record's ice concentration, so it is evaluated ONCE PER CELL when a record becomes resident
+// (same tests, same order, same left-to-right fp64 sum) and the crossing path reads one byte
+// instead of chasing two dependent 5-point stencils through memory.
+// ---------------------------------------------------------------------------
+template <typename FT>
+__global__ void survive_mask_kernel(int Nj, int Ni, const int8_t *__restrict__ tmask, const FT *__restrict__ sic,
+                                    double rmin_conc, int8_t *__restrict__ kill)
+{
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (size_t)Nj * Ni) return;
+    const int j = (int)(k / (size_t)Ni), i = (int)(k % (size_t)Ni);
+    kill[k] = survive_kill<FT>(j, i, Nj, Ni, tmask, sic, rmin_conc) ? 1 : 0;
+}
+
 __device__ __forceinline__ pt load_f(const CellGeo *__restrict__ geo, int j, int i, int Nj, int Ni)
 {
     return geo[(size_t)pywrap(j, Nj) * Ni + pywrap(i, Ni)].f;
 }
 
-// CrossedEdge + NewHostCell + UpdtInd4NewCell   reference sitrack/tracking.py:182-305
-// quad = [bl, br, ur, ul] of the current cell (jT,iT); returns the move (dj,di).
-__device__ __forceinline__ void new_host_cell(pt P1, pt P2, pt bl, pt br, pt ur, pt ul, int jT, int iT, int Nj, int Ni,
-                                              const CellGeo *__restrict__ geo, int &dj, int &di)
+// CrossedEdge + NewHostCell + UpdtInd4NewCell + Survive   reference sitrack/tracking.py:62-93,182-305
+// quad = [bl, br, ur, ul] of the current cell (jT,iT).  Returns the new packed cell (dead bit set when
+// Survive kills).  CrossedEdge needs only the quad (registers); everything that must come from memory
+// afterwards -- the two grid-line extension points of NewHostCell and the Survive bytes of the three
+// cells the buoy can have entered -- is then loaded in ONE batch of independent loads, so the crossing
+// path costs one memory round trip instead of a chain of four.
+__device__ __forceinline__ int32_t resolve_crossing(pt P1, pt P2, pt bl, pt br, pt ur, pt ul, int jT, int iT, int Nj, int Ni,
+                                                    const CellGeo *__restrict__ geo, const int8_t *__restrict__ kill,
+                                                    bool &killed)
 {
-    // CrossedEdge (:189-200): first of bottom, right, upper, left hit; falls through to 4
-    int kc;
-    if (intersect2seg(P1, P2, bl, br)) kc = 1;
-    else if (intersect2seg(P1, P2, br, ur)) kc = 2;
-    else if (intersect2seg(P1, P2, ur, ul)) kc = 3;
-    else kc = 4;
-    // NewHostCell (:217-243): the grid line prolonging the crossed edge beyond each end
-    int knhc = kc;
-    if (kc == 1) {
-        if (intersect2seg(P1, P2, bl, load_f(geo, jT - 2, iT - 1, Nj, Ni))) knhc = 5;
-        else if (intersect2seg(P1, P2, br, load_f(geo, jT - 2, iT, Nj, Ni))) knhc = 6;
-    } else if (kc == 2) {
-        if (intersect2seg(P1, P2, br, load_f(geo, jT - 1, iT + 1, Nj, Ni))) knhc = 6;
-        else if (intersect2seg(P1, P2, ur, load_f(geo, jT, iT + 1, Nj, Ni))) knhc = 7;
-    } else if (kc == 3) {
-        if (intersect2seg(P1, P2, ul, load_f(geo, jT + 1, iT - 1, Nj, Ni))) knhc = 8;
-        else if (intersect2seg(P1, P2, ur, load_f(geo, jT + 1, iT, Nj, Ni))) knhc = 7;
-    } else {
-        if (intersect2seg(P1, P2, ul, load_f(geo, jT, iT - 2, Nj, Ni))) knhc = 8;
-        else if (intersect2seg(P1, P2, bl, load_f(geo, jT - 1, iT - 2, Nj, Ni))) knhc = 5;
-    }
-    // UpdtInd4NewCell (:257-300)
-    //            1   2   3   4   5   6   7   8
-    dj = (knhc == 1 || knhc == 5 || knhc == 6) ? -1 : ((knhc == 3 || knhc == 7 || knhc == 8) ? 1 : 0);
-    di = (knhc == 4 || knhc == 5 || knhc == 8) ? -1 : ((knhc == 2 || knhc == 6 || knhc == 7) ? 1 : 0);
+    // CrossedEdge (:189-200): first of bottom, right, upper, left hit; falls through to 4.
+    // intersect2Seg(P1,P2,C,D) = (ccw(P1,C,D) != ccw(P2,C,D)) and (ccw(P1,P2,C) != ccw(P1,P2,D)); the second
+    // pair only involves one quad vertex each, so the four vertex terms are shared by adjacent edges.
+    const bool sbl = ccw(P1, P2, bl), sbr = ccw(P1, P2, br), sur = ccw(P1, P2, ur), sul = ccw(P1, P2, ul);
+    const bool h1 = (ccw(P1, bl, br) != ccw(P2, bl, br)) && (sbl != sbr);
+    const bool h2 = (ccw(P1, br, ur) != ccw(P2, br, ur)) && (sbr != sur);
+    const bool h3 = (ccw(P1, ur, ul) != ccw(P2, ur, ul)) && (sur != sul);
+    const int kc = h1 ? 1 : (h2 ? 2 : (h3 ? 3 : 4));
+    // NewHostCell (:217-243): segment vs the grid line prolonging the crossed edge beyond its two ends.
+    //   kc  first test (vertex -> ext. point) => code      second test                       => code   straight
+    //   1   bl -> F[jT-2,iT-1]  => 5 (-1,-1)                br -> F[jT-2,iT  ]  => 6 (-1,+1)           (-1, 0)
+    //   2   br -> F[jT-1,iT+1]  => 6 (-1,+1)                ur -> F[jT  ,iT+1]  => 7 (+1,+1)           ( 0,+1)
+    //   3   ul -> F[jT+1,iT-1]  => 8 (+1,-1)                ur -> F[jT+1,iT  ]  => 7 (+1,+1)           (+1, 0)
+    //   4   ul -> F[jT  ,iT-2]  => 8 (+1,-1)                bl -> F[jT-1,iT-2]  => 5 (-1,-1)           ( 0,-1)
+    const pt va = (kc == 1) ? bl : (kc == 2) ? br : ul;
+    const pt vb = (kc == 1) ? br : (kc == 4) ? bl : ur;
+    const int jA = (kc == 1) ? jT - 2 : (kc == 2) ? jT - 1 : (kc == 3) ? jT + 1 : jT;
+    const int iA = (kc == 1) ? iT - 1 : (kc == 2) ? iT + 1 : (kc == 3) ? iT - 1 : iT - 2;
+    const int jB = (kc == 1) ? jT - 2 : (kc == 2) ? jT : (kc == 3) ? jT + 1 : jT - 1;
+    const int iB = (kc == 1) ? iT : (kc == 2) ? iT + 1 : (kc == 3) ? iT : iT - 2;
+    const int djS = (kc == 1) ? -1 : (kc == 3) ? 1 : 0, diS = (kc == 2) ? 1 : (kc == 4) ? -1 : 0;
+    const int djA = (kc <= 2) ? -1 : 1, diA = (kc == 2) ? 1 : -1;          // codes 5,6,8,8
+    const int djB = (kc == 1 || kc == 4) ? -1 : 1, diB = (kc == 4) ? -1 : 1;   // codes 6,7,7,5
+    // one batch of independent loads
+    const pt eA = load_f(geo, jA, iA, Nj, Ni);
+    const pt eB = load_f(geo, jB, iB, Nj, Ni);
+    const int8_t kS = kill[(size_t)(jT + djS) * Ni + (iT + diS)];
+    const int8_t kA = kill[(size_t)(jT + djA) * Ni + (iT + diA)];
+    const int8_t kB = kill[(size_t)(jT + djB) * Ni + (iT + diB)];
+    const bool sva = (kc == 1) ? sbl : (kc == 2) ? sbr : sul;               // ccw(P1,P2,va), already known
+    const bool svb = (kc == 1) ? sbr : (kc == 4) ? sbl : sur;
+    const bool hitA = (ccw(P1, va, eA) != ccw(P2, va, eA)) && (sva != ccw(P1, P2, eA));
+    const bool hitB = (ccw(P1, vb, eB) != ccw(P2, vb, eB)) && (svb != ccw(P1, P2, eB));
+    // UpdtInd4NewCell (:257-300); first match wins (if / elif)
+    const int dj = hitA ? djA : (hitB ? djB : djS);
+    const int di = hitA ? diA : (hitB ? diB : diS);
+    killed = (hitA ? kA : (hitB ? kB : kS)) != 0;                           // Survive (:483-484)
+    int32_t cn = pack_cell(jT + dj, iT + di);
+    if (killed) cn |= SITRK_DEAD_BIT;
+    return cn;
 }
 
-// performance knobs (never change results)
-enum : int {
-    TUNE_XCD_REMAP = 1,    // give each XCD a contiguous chunk of the sorted buoys (neighbour rows hit the same L2)
-    TUNE_NT_STATE = 2,     // stream pos/cell with non-temporal loads/stores: they are touched once per step
-    TUNE_COMPACT = 4,      // workgroup compaction of the crossing path (advect_step_compact_kernel)
-    TUNE_LOCATE_BRUTEFORCE = 8,   // SeedInit: whole-grid Haversine scan per seed (the reference's algorithm) instead of the sphere search
-};
 
 typedef double v2d __attribute__((ext_vector_type(2)));
 
@@ -126,8 +155,8 @@ struct StepArgs {
     int jrec;
     double rdt, rmin_conc;
     const CellGeo *geo;
-    const int8_t *tmask;
-    const void *u, *v, *sic;
+    const int8_t *kill;                 // the record's Survive mask (survive_mask_kernel)
+    const void *u, *v;
     pt *pos;
     int32_t *cell;
     int32_t *kill_rec;
@@ -190,131 +219,65 @@ __global__ __launch_bounds__(kBlock) void advect_step_kernel(StepArgs a)
 
     // still inside the host cell? (:466) quad = [bl, br, ur, ul]
     if (!inside_quad(Pn.y, Pn.x, F00, F01, g11.f, F10)) {
-        int dj, di;
-        new_host_cell(P, Pn, F00, F01, g11.f, F10, jT, iT, Nj, Ni, a.geo, dj, di);
-        const int jN = jT + dj, iN = iT + di;
-        int32_t cn = pack_cell(jN, iN);
-        if (survive_kill<FT>(jN, iN, Nj, Ni, a.tmask, (const FT *)a.sic, a.rmin_conc)) {   // :483-484
-            cn |= SITRK_DEAD_BIT;
-            a.kill_rec[p] = a.jrec;
-        }
+        bool killed;
+        const int32_t cn = resolve_crossing(P, Pn, F00, F01, g11.f, F10, jT, iT, Nj, Ni, a.geo, a.kill, killed);
+        if (killed) a.kill_rec[p] = a.jrec;
         a.cell[p] = cn;
     }
 }
 
+#ifdef SITRK_DIAG
 // ---------------------------------------------------------------------------
-// Same record step with WORKGROUP COMPACTION OF THE CROSSING PATH.
-//
-// Only 3-16 % of buoys leave their cell in a step, but almost every wavefront has at least
-// one that does, so in the one-pass kernel every wave pays the whole CrossedEdge /
-// NewHostCell / Survive instruction stream (~45 % of its fp64 work; fp64 issues at 16
-// lanes/clk, 4 cycles per wave64 instruction, and this kernel is as VALU-heavy as it is
-// HBM-heavy) for a handful of active lanes.  Here the lanes that crossed append
-// (buoy, old position, new position, cell) to an LDS queue (one LDS atomic per wave, ballot +
-// popcount for the slot), and after one barrier the queue is drained by densely packed lanes:
-// typically ONE wave of the four does the crossing work of the whole workgroup.
-// Buoys are independent, so the queue order does not matter: results are bit-identical.
+// ABLATION KERNELS (diagnostic builds only, `make DIAG=1`; results are WRONG by design).
+//   memonly : issues exactly the loads/stores of the hot path, no predicates  -> memory-side time
+//   nocross : the hot path without CrossedEdge/NewHostCell/Survive            -> price of the crossing path
 // ---------------------------------------------------------------------------
-struct CrossItem {
-    pt P, Pn;          // position before / after the Euler step
-    int32_t cell;      // packed host cell before the move
-    int32_t slot;      // index within the workgroup's 256 buoys
-};
-
-template <typename FT, int UVS, bool WINDOW>
-__global__ __launch_bounds__(kBlock) void advect_step_compact_kernel(StepArgs a)
+template <typename FT>
+__global__ __launch_bounds__(kBlock) void advect_memonly_kernel(StepArgs a)
 {
-    __shared__ CrossItem queue[kBlock];
-    __shared__ int qcount;
-    if (threadIdx.x == 0) qcount = 0;
-    __syncthreads();
-
-    const unsigned blk = (a.tune & TUNE_XCD_REMAP) ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
-    const int64_t p0 = (int64_t)blk * kBlock;
-    const int64_t p = p0 + threadIdx.x;
-    const bool nt = (a.tune & TUNE_NT_STATE) != 0;
-    const int Ni = a.Ni, Nj = a.Nj;
-
-    bool active = p < a.nP;
-    int32_t c = 0;
-    if (active) {
-        c = nt ? __builtin_nontemporal_load(&a.cell[p]) : a.cell[p];
-        active = c >= 0;                                   // iAlive == 1
-    }
-    if (WINDOW) {
-        if (active) active = (a.jrec >= a.first[p]) && (a.jrec <= a.last[p]);
-    }
-
-    bool crossed = false;
-    pt P = make_pt(0., 0.), Pn = P;
-    if (active) {
-        const int jT = cell_j(c), iT = cell_i(c);
-        const size_t k = (size_t)jT * Ni + iT;
-        const FT *__restrict__ u = (const FT *)a.u;
-        const FT *__restrict__ v = (const FT *)a.v;
-        P = nt ? load_pt_nt(&a.pos[p]) : a.pos[p];
-        const CellGeo g11 = a.geo[k];
-        const pt F10 = a.geo[k - 1].f;
-        const pt F01 = a.geo[k - Ni].f;
-        const pt F00 = a.geo[k - Ni - 1].f;
-        double zU, zV;
-        if (UVS == 0) {                                      // :423-425
-            zU = 0.5 * ((double)u[k] + (double)u[k - 1]);
-            zV = 0.5 * ((double)v[k] + (double)v[k - Ni]);
-        } else {                                             // :427-441
-            const pt U10 = a.geo[k - 1].u;
-            const pt V01 = a.geo[k - Ni].v;
-            const double u1 = (double)u[k], u0 = (double)u[k - 1];
-            const double v1 = (double)v[k], v0 = (double)v[k - Ni];
-            const bool llum1 = intersect2seg(P, g11.f, V01, g11.v);
-            const bool llvm1 = intersect2seg(P, g11.f, U10, g11.u);
-            zU = llum1 ? u0 : u1;
-            zV = llvm1 ? v0 : v1;
-        }
-        const double dx = zU * a.rdt;                        // :452-458
-        const double dy = zV * a.rdt;
-        Pn.x = P.x + dx / 1000.;
-        Pn.y = P.y + dy / 1000.;
-        if (nt) store_pt_nt(&a.pos[p], Pn);                  // :459-460
-        else a.pos[p] = Pn;
-        crossed = !inside_quad(Pn.y, Pn.x, F00, F01, g11.f, F10);   // :466
-    }
-
-    // ---- enqueue the lanes that left their cell
-    const unsigned long long m = __ballot(crossed);
-    if (m) {
-        const int lane = threadIdx.x & 63;
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&qcount, __popcll(m));
-        base = __shfl(base, 0);
-        if (crossed) {
-            const int at = base + __popcll(m & ((1ull << lane) - 1ull));
-            CrossItem it;
-            it.P = P; it.Pn = Pn; it.cell = c; it.slot = (int32_t)threadIdx.x;
-            queue[at] = it;
-        }
-    }
-    __syncthreads();
-
-    // ---- drain: CrossedEdge / NewHostCell / UpdtInd4NewCell / Survive (:474-484) on dense lanes
-    const int n = qcount;
-    for (int t = threadIdx.x; t < n; t += kBlock) {
-        const CrossItem it = queue[t];
-        const int jT = cell_j(it.cell), iT = cell_i(it.cell);
-        const size_t k = (size_t)jT * Ni + iT;
-        const pt F11 = a.geo[k].f, F10 = a.geo[k - 1].f, F01 = a.geo[k - Ni].f, F00 = a.geo[k - Ni - 1].f;
-        int dj, di;
-        new_host_cell(it.P, it.Pn, F00, F01, F11, F10, jT, iT, Nj, Ni, a.geo, dj, di);
-        const int jN = jT + dj, iN = iT + di;
-        int32_t cn = pack_cell(jN, iN);
-        const int64_t q = p0 + it.slot;
-        if (survive_kill<FT>(jN, iN, Nj, Ni, a.tmask, (const FT *)a.sic, a.rmin_conc)) {
-            cn |= SITRK_DEAD_BIT;
-            a.kill_rec[q] = a.jrec;
-        }
-        a.cell[q] = cn;
-    }
+    int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= a.nP) return;
+    int32_t c = a.cell[p];
+    if (c < 0) return;
+    const int Ni = a.Ni;
+    const size_t k = (size_t)cell_j(c) * Ni + cell_i(c);
+    const FT *__restrict__ u = (const FT *)a.u;
+    const FT *__restrict__ v = (const FT *)a.v;
+    const pt P = a.pos[p];
+    const CellGeo g11 = a.geo[k];
+    const pt F10 = a.geo[k - 1].f, U10 = a.geo[k - 1].u, F01 = a.geo[k - Ni].f, V01 = a.geo[k - Ni].v, F00 = a.geo[k - Ni - 1].f;
+    const double s = (double)u[k] + (double)u[k - 1] + (double)v[k] + (double)v[k - Ni];
+    pt Pn;
+    Pn.y = P.y + 1e-300 * (g11.f.y + g11.u.y + g11.v.y + F10.y + U10.y + F01.y + V01.y + F00.y + s);
+    Pn.x = P.x + 1e-300 * (g11.f.x + g11.u.x + g11.v.x + F10.x + U10.x + F01.x + V01.x + F00.x);
+    a.pos[p] = Pn;
 }
+
+template <typename FT>
+__global__ __launch_bounds__(kBlock) void advect_nocross_kernel(StepArgs a)
+{
+    int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= a.nP) return;
+    int32_t c = a.cell[p];
+    if (c < 0) return;
+    const int Ni = a.Ni;
+    const size_t k = (size_t)cell_j(c) * Ni + cell_i(c);
+    const FT *__restrict__ u = (const FT *)a.u;
+    const FT *__restrict__ v = (const FT *)a.v;
+    const pt P = a.pos[p];
+    const CellGeo g11 = a.geo[k];
+    const pt F10 = a.geo[k - 1].f, U10 = a.geo[k - 1].u, F01 = a.geo[k - Ni].f, V01 = a.geo[k - Ni].v, F00 = a.geo[k - Ni - 1].f;
+    const double u1 = (double)u[k], u0 = (double)u[k - 1], v1 = (double)v[k], v0 = (double)v[k - Ni];
+    const bool llum1 = intersect2seg(P, g11.f, V01, g11.v);
+    const bool llvm1 = intersect2seg(P, g11.f, U10, g11.u);
+    const double zU = llum1 ? u0 : u1, zV = llvm1 ? v0 : v1;
+    pt Pn;
+    Pn.x = P.x + (zU * a.rdt) / 1000.;
+    Pn.y = P.y + (zV * a.rdt) / 1000.;
+    a.pos[p] = Pn;
+    if (!inside_quad(Pn.y, Pn.x, F00, F01, g11.f, F10)) a.cell[p] = c ^ 1;      // keep the test alive, skip the rest
+}
+#endif  // SITRK_DIAG
 
 // ---------------------------------------------------------------------------
 // state upload helpers / sort support
@@ -325,14 +288,25 @@ __global__ void iota_kernel(int64_t n, int32_t *v)
     if (s < n) v[s] = (int32_t)s;
 }
 
-// key = row-major cell index; dead buoys last
-__global__ void make_keys_kernel(int64_t n, int Ni, uint32_t dead_key, const int32_t *__restrict__ cell,
+// Sort key of a host cell; dead buoys last.  tj == 0: row-major cell index.  Otherwise tile-major:
+// tiles of tj x ti cells in row-major order, row-major inside a tile, so that a workgroup's 256 buoys
+// cover a compact 2-D patch (rows j-1..j of the patch are shared inside the workgroup instead of being
+// fetched twice by workgroups a whole grid row apart).
+__host__ __device__ __forceinline__ uint32_t cell_key(int j, int i, int Ni, int tj, int ti)
+{
+    if (tj == 0) return (uint32_t)j * (uint32_t)Ni + (uint32_t)i;
+    const uint32_t nti = ((uint32_t)Ni + (uint32_t)ti - 1u) / (uint32_t)ti;
+    const uint32_t tile = ((uint32_t)j / (uint32_t)tj) * nti + (uint32_t)i / (uint32_t)ti;
+    return tile * (uint32_t)(tj * ti) + ((uint32_t)j % (uint32_t)tj) * (uint32_t)ti + (uint32_t)i % (uint32_t)ti;
+}
+
+__global__ void make_keys_kernel(int64_t n, int Ni, int tj, int ti, uint32_t dead_key, const int32_t *__restrict__ cell,
                                  uint32_t *__restrict__ keys, int32_t *__restrict__ vals)
 {
     int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
     int32_t c = cell[s];
-    keys[s] = (c < 0) ? dead_key : (uint32_t)cell_j(c) * (uint32_t)Ni + (uint32_t)cell_i(c);
+    keys[s] = (c < 0) ? dead_key : cell_key(cell_j(c), cell_i(c), Ni, tj, ti);
     vals[s] = (int32_t)s;
 }
 

@@ -58,8 +58,9 @@ def broadcast_record(ctx, slot, slab_host, src=0, group=None, async_op=False):
         t.copy_(torch.from_numpy(slab_host), non_blocking=False)
     work = dist.broadcast(t, src=src, group=group, async_op=async_op)
     if async_op:
-        return work
+        return work                    # caller: work.wait(), order the streams, then ctx.commit_record(slot)
     torch.cuda.current_stream().synchronize()
+    ctx.commit_record(slot)            # derive the record's Survive mask from the new slab
     return None
 
 

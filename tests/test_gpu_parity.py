@@ -127,12 +127,13 @@ def test_tuning_knobs_do_not_change_results():
     u, v, sic = syn.make_fields(grid, K=3, seed=8, umax=0.7, drift=0.2, ripple=0.1)
     _, yx = syn.make_buoys(grid, 30011, seed=21, frac=0.7)
     res = []
-    for knobs in ({}, {"xcd_remap": 1}, {"nt_state": 1}, {"xcd_remap": 1, "nt_state": 1}, {"compact": 1},
-                  {"compact": 1, "nt_state": 1, "xcd_remap": 1}):
+    for knobs in ({}, {"xcd_remap": 1}, {"nt_state": 1}, {"xcd_remap": 1, "nt_state": 1}, {"sort_tile": 8 * 256 + 32},
+                  {"sort_tile": 5 * 256 + 7, "nt_state": 1, "xcd_remap": 1}):
         trk = make_tracker(grid, grid["tmask"], 3)
         found, ji, _ = sit.FindContainingCell(yx, syn.nearest_t_plane(grid, yx), ctx=trk.ctx)
-        trk.set_buoys(yx[found], ji[found])
         trk.ctx.set_tuning(**knobs)
+        trk.set_buoys(yx[found], ji[found])
+        trk.ctx.set_resort(6)
         for k in range(3):
             trk.load_record(k, u[k], v[k], sic[k])
         trk.ctx.run(0, 0, 25)

@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--knobs", default="xcd_remap,nt_state")
+    ap.add_argument("--tiles", default="", help="comma list of tile_jxtile_i sort orders to add as variants, e.g. 8x32,16x16")
+    ap.add_argument("--base", default="", help="knob=value,... applied to every variant")
+    ap.add_argument("--singles", default="", help="extra variants, one knob each (e.g. diag_memonly,diag_nocross); no result check")
     a = ap.parse_args()
     N, nP, K = a.grid, a.buoys, 8
     grid = syn.make_grid(N, N, dkm=4.0, warp=0.0)
@@ -38,19 +41,28 @@ def main():
         ctx.push_record(k, u[k], v[k], sic[k])
     knobs = [k for k in a.knobs.split(",") if k]
     variants = [dict(zip(knobs, bits)) for bits in itertools.product((0, 1), repeat=len(knobs))]
+    singles = [k for k in a.singles.split(",") if k]
+    allk = knobs + singles
+    variants = [dict({k: 0 for k in allk}, **v) for v in variants] + [dict({k: 0 for k in allk}, **{k: 1}) for k in singles]
+    base = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in a.base.split(",") if kv)
+    variants = [dict(v, sort_tile=0) for v in variants]
+    for t in [t for t in a.tiles.split(",") if t]:
+        tj, ti = (int(x) for x in t.split("x"))
+        variants.append(dict({k: 0 for k in allk}, sort_tile=tj * 256 + ti))
+    variants = [dict(v, **base) for v in variants]
     times = {i: [] for i in range(len(variants))}
     ref = None
     for rnd in range(a.rounds):
         for i, var in enumerate(variants):
-            ctx.set_buoys(yx, ji)                  # same start every time
             ctx.set_tuning(**var)
+            ctx.set_buoys(yx, ji)                  # same start every time (sorted with the variant's key)
             ctx.run(0, 0, 10)
             ctx.sync()
             ctx.timer_start()
             ctx.run(10 % K, 10, a.steps)
             ms = ctx.timer_stop()
             times[i].append(ms / a.steps)
-            if rnd == 0:
+            if rnd == 0 and not any(var.get(k) for k in singles):
                 st = ctx.fetch(("yx", "jiT"))
                 if ref is None:
                     ref = st
