@@ -1,0 +1,249 @@
+"""Command-line driver: the reference's `si3_part_tracker.py` surface on top of libsitrk.
+
+Same flags and defaults (reference si3_part_tracker.py:42-73), same module constants
+(`rdt = 3600`, `iUVstrategy = 1`, :31,37), same file-name logic (:115-148,510-517,565-568), same
+`./seed/Initialized_buoys_<SeedName>_<CONF>.npz` cache keys (:205-255), same per-buoy record windows in
+2-D-time mode (:264-318), same NetCDF outputs (:515-571) -- the per-buoy loop (:378-490) and the
+per-record inverse projection (:493) run on the GPU.  Differences, all opt-in or forced:
+extra flags `--device`, `--uv-strategy`; errors raise instead of `print; exit(0)`; maps need the
+optional `mojito` package and are skipped without it; the full (Nt+1,nP,2) series is only kept in
+host memory when it is written (`-F`) instead of always (the reference's 320 GB at 1e7 buoys x 1000 records).
+"""
+import argparse
+import os
+from datetime import datetime, timezone
+from os import path
+
+import numpy as np
+
+from . import _lib, ncio
+from .tracking import GetTimeSpan, IceTracker, SeedInit
+
+rdt = 3600.          # time step [s] = model output period (reference :31)
+FILL = ncio.FillValue
+
+
+def epoch2clock(it):
+    """reference util.py:18-34 (precision 's')"""
+    return datetime.fromtimestamp(int(it), timezone.utc).strftime("%Y-%m-%d_%H:%M:%S")
+
+
+def clock2epoch(cdate):
+    """'YYYY-MM-DD_hh:mm:ss' (reference util.py:36-40) or a bare day 'YYYY-MM-DD' / 'YYYYMMDD' (mojito's 'guess')."""
+    for fmt in ("%Y-%m-%d_%H:%M:%S", "%Y-%m-%d", "%Y%m%d"):
+        try:
+            return int(datetime.strptime(cdate, fmt).replace(tzinfo=timezone.utc).timestamp())
+        except ValueError:
+            pass
+    raise ValueError("cannot parse date '%s'" % cdate)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser(description='SITRACK ICE PARTICULES TRACKER (MI355X build)')
+    rq = ap.add_argument_group('required arguments')
+    rq.add_argument('-i', '--fsi3', required=True, help='output file of SI3 containing ice velocities ans co')
+    rq.add_argument('-m', '--fmmm', required=True, help='model `mesh_mask` file of NEMO config used in SI3 run')
+    rq.add_argument('-s', '--fsdg', required=True, help='seeding file')
+    ap.add_argument('-k', '--krec', type=int, default=0, help='record of seeding file to use to seed from')
+    ap.add_argument('-e', '--dend', default=None, help='date at which to stop')
+    ap.add_argument('-F', '--fxdt', action="store_true", help='fixed tracking time (1D time array)')
+    ap.add_argument('-N', '--ncnf', default='NANUK4', help='name of the horizontak NEMO config used')
+    ap.add_argument('-p', '--plot', type=int, default=0, help='how often, in terms of model records, we plot the positions on a map')
+    ap.add_argument('--device', type=int, default=0, help='GPU to use (extra)')
+    ap.add_argument('--uv-strategy', type=int, default=1, choices=(0, 1), help='iUVstrategy of the reference, default 1 (extra)')
+    return ap.parse_args(argv)
+
+
+def seed_name_tokens(fNCseedBN):
+    """`cdtbin`, `csfkm` from the seeding file NAME (reference :115-148)."""
+    stem = fNCseedBN.split('.')[0].split('_')
+    csfkm = ''
+    if len(stem) > 2 and stem[2] in ('nemoTsi3', 'nemoTmm', 'sidfex'):
+        cdtbin = '_idlSeed'
+        for ii in (1, 2, 3):
+            ckm = '_' + stem[-ii]
+            if ckm[-2:] == 'km':
+                csfkm = ckm
+                break
+    else:
+        toks = fNCseedBN.split('.')[-2].split('_')
+        itst, lok = 1, False
+        while not lok:
+            itst -= 1
+            csfkm = '_' + toks[itst]
+            cdtbin = '_' + toks[-3 + itst]
+            lok = (csfkm[-2:] == 'km' and cdtbin[1:3] == 'dt') or (cdtbin[1:3] == 'dt' and itst == 0)
+            if itst < -4:
+                raise ValueError('could not figure out `csfkm` and `cdtbin` from file name! %s %s' % (csfkm, cdtbin))
+        if itst == 0:
+            csfkm = ''
+    return cdtbin, csfkm
+
+
+def date_tag(it):
+    """'1996-12-15_00:00:00' -> '19961215h00' (reference :510-512)"""
+    c = epoch2clock(it).split(':')[0]
+    return c.replace('-', '').replace('_', 'h')
+
+
+def record_windows(zTpos, ztime_model, kstrt, kstop, iTmA, iTmB, nP):
+    """Per-buoy first / last model record in 2-D-time mode (reference :264-312)."""
+    z1st = np.zeros(nP, dtype=int) + kstrt
+    zLst = np.zeros(nP, dtype=int) + kstop
+    half = int(rdt / 2)
+    for jb in np.where(zTpos[0, :] >= iTmA + half)[0]:
+        (idx,) = np.where(ztime_model + half < zTpos[0, jb])
+        z1st[jb] = idx[-1] + 1
+    for jb in np.where(zTpos[1, :] < iTmB - half)[0]:
+        (idx,) = np.where(ztime_model - half > zTpos[1, jb])
+        zLst[jb] = idx[0] - 1
+    return z1st, zLst
+
+
+def main(argv=None):
+    a = parse_args(argv)
+    cf_uv, cf_mm, fNCseed, jrecSeed, cdate_stop, CONF = a.fsi3, a.fmmm, a.fsdg, a.krec, a.dend, a.ncnf
+    lUse2DTime = not a.fxdt
+    iUVstrategy = a.uv_strategy
+    print('\n *** SITRACK ice particule tracker, GPU build; NetCDF backend = ' + ncio.backend())
+    print(' *** SI3 file =>', cf_uv, '\n *** mesh_mask =>', cf_mm, '\n *** seeding  =>', fNCseed, jrecSeed)
+
+    cdtbin, csfkm = seed_name_tokens(path.basename(fNCseed))
+    idateSeedA, idateSeedB, SeedName, SeedBatch, zTpos = ncio.SeedFileTimeInfo(fNCseed, ltime2d=lUse2DTime)
+    Nt0, ztime_model, idateModA, idateModB, ModConf, ModExp = ncio.ModelFileTimeInfo(cf_uv)
+
+    date_stop = None
+    if cdate_stop:
+        date_stop = clock2epoch(cdate_stop)
+    elif idateSeedB - idateSeedA >= 3600.:
+        date_stop = idateSeedB                      # several records in the seeding file: replicate its time span (:168-172)
+    Nt, kstrt, kstop, iTmA, iTmB = GetTimeSpan(rdt, ztime_model, idateSeedA, idateModA, idateModB, iStop=date_stop)
+    if Nt < 1:
+        print(' QUITTING since no matching model records!')
+        return 0
+    print(' *** model records %d..%d (%d records): %s -> %s' % (kstrt, kstop, Nt, epoch2clock(iTmA), epoch2clock(iTmB)))
+    for cd in ('seed', 'nc', 'npz'):
+        os.makedirs(cd, exist_ok=True)
+
+    ctx = _lib.Context(a.device)
+    imaskt, xlatT, xlonT, xYt, xXt, xYf, xXf, xResKM = ncio.GetModelGrid(cf_mm, ctx)
+    if iUVstrategy == 1:
+        xYv, xXv, xYu, xXu = ncio.GetModelUVGrid(cf_mm, ctx)
+    else:
+        xYv, xXv, xYu, xXu = xYf, xXf, xYf, xXf     # never read by the cell-mean rule
+    (Nj, Ni) = np.shape(imaskt)
+    records = ncio.ModelRecords(cf_uv)
+
+    # ---- seeding, with the reference's intermediate cache (:205-255)
+    cf_npz_itm = './seed/Initialized_buoys_' + SeedName + '_' + CONF + '.npz'
+    if path.exists(cf_npz_itm):
+        print(' *** using cached seed initialisation ' + cf_npz_itm)
+        with np.load(cf_npz_itm) as data:
+            nP = int(data['nP']); xPosG0 = data['xPosG0']; xPosC0 = data['xPosC0']; IDs = data['IDs']
+            vJIt = data['vJIt']; VRTCS = data['VRTCS']; idxK = data['idxKeep']
+    else:
+        (xIC,) = records.fields(kstrt, ('siconc',))
+        zt, zIDs, XseedG, XseedC = ncio.LoadNCdata(fNCseed, krec=jrecSeed)
+        (nP0, _) = np.shape(XseedG)
+        IDs = np.array(zIDs, dtype=int)
+        nP, xPosG0, xPosC0, IDs, vJIt, VRTCS, idxK = SeedInit(IDs, XseedG, XseedC, xlatT, xlonT, xYf, xXf, xResKM, imaskt,
+                                                              xIceConc=np.asarray(xIC, dtype=np.float64), ctx=ctx)
+        if nP < nP0:
+            print(' *** `SeedInit()` had to cancel ' + str(nP0 - nP) + ' buoys! => nP = ' + str(nP))
+        np.savez_compressed(cf_npz_itm, nP=nP, xPosG0=xPosG0, xPosC0=xPosC0, IDs=IDs, vJIt=vJIt, VRTCS=VRTCS, idxKeep=idxK)
+
+    # ---- per-buoy record windows (:264-318)
+    z1stModelRec = np.zeros(nP, dtype=int) + kstrt
+    zLstModelRec = np.zeros(nP, dtype=int) + kstop
+    if lUse2DTime:
+        zTpos = np.asarray(zTpos)
+        if zTpos.shape != (2, nP):
+            raise ValueError('wrong shape for the 2D time array `zTpos`: %s vs nP=%d' % (zTpos.shape, nP))
+        z1stModelRec, zLstModelRec = record_windows(zTpos, ztime_model, kstrt, kstop, iTmA, iTmB, nP)
+    k0 = z1stModelRec - kstrt
+
+    # ---- device state
+    (u0,) = records.fields(kstrt, ('u_ice',))
+    fdt = np.float64 if np.asarray(u0).dtype == np.float64 else np.float32
+    trk = IceTracker(xYf, xXf, xYu, xXu, xYv, xXv, imaskt, rdt=rdt, iUVstrategy=iUVstrategy, nslots=1, field_dtype=fdt, ctx=ctx)
+    trk.set_buoys(xPosC0, vJIt, z1stModelRec if lUse2DTime else None, zLstModelRec if lUse2DTime else None)
+
+    # ---- host arrays: the full series only when it is written
+    lFull = (not lUse2DTime) or a.plot > 0
+    vTime = np.zeros(Nt + 1, dtype=int)
+    if lFull:
+        xmask = np.zeros((Nt + 1, nP), dtype='i1')
+        xPosC = np.zeros((Nt + 1, nP, 2)) + FILL
+        xPosG = np.zeros((Nt + 1, nP, 2)) + FILL
+        xPosC[k0, np.arange(nP), :] = xPosC0
+        xPosG[k0, np.arange(nP), :] = xPosG0
+        xmask[k0, np.arange(nP)] = 1
+    if lUse2DTime:
+        z2XY, z2GC = np.zeros((2, nP, 2)) + FILL, np.zeros((2, nP, 2)) + FILL
+        zMSK, zTim = np.zeros((2, nP), dtype='i1'), np.zeros((2, nP), dtype=int) + int(FILL)
+        z2XY[0], z2GC[0], zMSK[0] = xPosC0, xPosG0, 1
+        zTim[0] = ztime_model[z1stModelRec] - int(rdt / 2)
+        # a buoy whose window opens later has its seed position pre-written at record k0, and the reference converts
+        # that row to lat/lon when it passes over record k0-1 (:493)
+        late = k0 > 0
+        if np.any(late):
+            z2GC[0, late] = ctx.cart2geo(xPosC0[late])
+        ends = set(np.unique(zLstModelRec).tolist())
+
+    # ---- the record loop (:361-496)
+    for jt in range(Nt):
+        jrec = jt + kstrt
+        itmod = records.time(jrec)
+        itime = itmod - int(rdt / 2.)
+        vTime[jt] = itime
+        xUu, xVv, xIC = records.fields(jrec)
+        print(' *** record #%d/%d  date = %s   buoys alive = %d' % (jrec + 1, Nt0, epoch2clock(itime), trk.alive_count()))
+        trk.load_record(0, xUu, xVv, xIC)
+        trk.step(jrec, 0)
+        need = lFull or (lUse2DTime and jrec in ends)
+        if need:
+            pos, msk = trk.record(jrec)
+            stepped = msk == 1
+        if lFull:
+            xPosC[jt + 1, stepped] = pos[stepped]
+            xmask[jt + 1, stepped] = 1
+            xPosG[jt + 1] = ctx.cart2geo(xPosC[jt + 1])
+        if lUse2DTime and jrec in ends:
+            sel = np.where(zLstModelRec == jrec)[0]
+            z2XY[1, sel] = pos[sel]
+            z2GC[1, sel] = ctx.cart2geo(pos[sel])
+            zMSK[1, sel] = msk[sel]
+            zTim[1, sel[stepped[sel]]] = int(itime + rdt)
+    records.close()
+    vTime[Nt] = vTime[Nt - 1] + int(rdt)
+
+    # ---- outputs (:509-571)
+    corgn = 'NEMO-SI3_' + ModConf + '_' + ModExp
+    outs = []
+    if not lUse2DTime:
+        cf_nc_out = './nc/' + corgn + '_tracking_' + SeedBatch + cdtbin + '_' + date_tag(vTime[0]) + '_' + date_tag(vTime[Nt]) + csfkm + '.nc'
+        ncio.ncSaveCloudBuoys(cf_nc_out, vTime, IDs, xPosC[:, :, 0], xPosC[:, :, 1], xPosG[:, :, 0], xPosG[:, :, 1],
+                              mask=xmask, corigin=corgn)
+        outs.append(cf_nc_out)
+        z2XY = np.stack([xPosC[0], xPosC[Nt]]); z2GC = np.stack([xPosG[0], xPosG[Nt]]); zMSK = np.stack([xmask[0], xmask[Nt]])
+        zTim = []
+        zvt = np.array([vTime[0], vTime[Nt]])
+    else:
+        zvt = np.array([np.mean(zTim[0, :]), np.mean(zTim[1, :])])
+    cf_nc_out = './nc/' + corgn + '_tracking12_' + SeedBatch + cdtbin + '_' + date_tag(zvt[0]) + '_' + date_tag(zvt[1]) + csfkm + '.nc'
+    ncio.ncSaveCloudBuoys(cf_nc_out, zvt, IDs, z2XY[:, :, 0], z2XY[:, :, 1], z2GC[:, :, 0], z2GC[:, :, 1], mask=zMSK, xtime=zTim,
+                          corigin=corgn)
+    outs.append(cf_nc_out)
+
+    if a.plot > 0:
+        try:
+            import mojito as mjt          # noqa: F401  optional, as in the reference (:20,587-600)
+            print(' *** `mojito` found: map plotting is left to the reference tooling (positions are in ' + outs[0] + ')')
+        except Exception:                 # noqa: BLE001
+            print(' *** `-p`: package `mojito` not available here => no maps (positions are in ' + outs[0] + ')')
+    print(' *** first and final dates in simulated trajectories:', epoch2clock(zvt[0]), epoch2clock(zvt[1]))
+    for f in outs:
+        print('      ===> ' + f + ' saved!')
+    state = trk.state()
+    trk.close()
+    return {"files": outs, "nP": nP, "IDs": IDs, "vJIt": state["vJIt"], "iAlive": state["iAlive"], "Nt": Nt, "kstrt": kstrt}

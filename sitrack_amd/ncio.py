@@ -1,0 +1,305 @@
+"""NetCDF input/output for the driver -- host-side mirror of reference `sitrack/ncio.py`.
+
+Same function names, arguments and return values as the reference, same on-disk schema
+(reference ncio.py:131-197 for trajectory/seeding files, :22-92 for the NEMO `mesh_mask`,
+si3_part_tracker.py:365-374 for the `icemod` records).  Two differences, both forced by
+the environment: (1) the geographic -> polar-stereographic conversion goes through
+libsitrk's projection kernel instead of cartopy; (2) the reference's hard dependency on the
+`netCDF4` package becomes optional: when it is absent, NetCDF-3 (classic / 64-bit offset)
+files are read and written with `scipy.io.netcdf_file`.  NetCDF-3 has no int64 and no
+compression, so in that fall-back `id_buoy` is stored as float64 (exact up to 2^53; buoy IDs
+reach 3e14) and `zlib` is dropped; everything else is identical.
+"""
+import os
+from os import path
+
+import numpy as np
+
+tunits_default = 'seconds since 1970-01-01 00:00:00'      # reference ncio.py:15
+FillValue = -9999.                                         # reference ncio.py:19
+
+try:                                                       # pragma: no cover - depends on the environment
+    import netCDF4 as _nc4
+except Exception:                                          # noqa: BLE001
+    _nc4 = None
+
+
+def backend():
+    return "netCDF4" if _nc4 is not None else "scipy-netcdf3"
+
+
+def chck4f(cf):
+    if not path.exists(cf):
+        raise FileNotFoundError(' ERROR [chck4f()]: file ' + cf + ' does not exist!')
+
+
+class _Reader:
+    """Minimal uniform read access: var(name)[index] -> ndarray, attr(name, att), dim(name)."""
+
+    def __init__(self, cfile):
+        chck4f(cfile)
+        self.nc4 = None
+        self.sp = None
+        if _nc4 is not None:
+            try:
+                self.nc4 = _nc4.Dataset(cfile)
+            except Exception:                              # noqa: BLE001  (e.g. classic file and odd build)
+                self.nc4 = None
+        if self.nc4 is None:
+            from scipy.io import netcdf_file
+            self.sp = netcdf_file(cfile, 'r', mmap=False, maskandscale=False)
+
+    def has_var(self, name):
+        return name in (self.nc4.variables if self.nc4 is not None else self.sp.variables)
+
+    def has_dim(self, name):
+        return name in (self.nc4.dimensions if self.nc4 is not None else self.sp.dimensions)
+
+    def dim(self, name):
+        if self.nc4 is not None:
+            return self.nc4.dimensions[name].size
+        n = self.sp.dimensions[name]
+        if n is None:                                      # record dimension
+            n = self.sp._recs
+        return int(n)
+
+    def var(self, name, index=Ellipsis):
+        if self.nc4 is not None:
+            v = self.nc4.variables[name]
+            v.set_auto_mask(False)                         # raw values: the reference assigns masked slabs into plain arrays
+            return np.array(v[index])
+        return np.array(self.sp.variables[name][index])
+
+    def attr(self, name, att):
+        v = (self.nc4 if self.nc4 is not None else self.sp).variables[name]
+        a = getattr(v, att)
+        return a.decode() if isinstance(a, bytes) else a
+
+    def close(self):
+        (self.nc4 if self.nc4 is not None else self.sp).close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def _project(ctx, lat, lon):
+    """ConvertGeo2CartesianNPSkm (reference util.py:434-451): lat/lon (deg, 2-D) -> (Y, X) km, lat_ts 70, lon_0 -45."""
+    shp = np.shape(lat)
+    ll = np.stack([np.asarray(lat, dtype=np.float64).ravel(), np.asarray(lon, dtype=np.float64).ravel()], axis=1)
+    yx = ctx.geo2cart(ll, 70., -45.)
+    return np.ascontiguousarray(yx[:, 0].reshape(shp)), np.ascontiguousarray(yx[:, 1].reshape(shp))
+
+
+def GetModelGrid(fNCmeshmask, ctx):
+    """Reference ncio.py:22-63 -> kmaskt, zlatT, zlonT, zYt, zXt, zYf, zXf, zResKM."""
+    with _Reader(fNCmeshmask) as f:
+        kmaskt = f.var('tmask', (0, 0))
+        zlonF = f.var('glamf', 0); zlatF = f.var('gphif', 0)
+        zlonT = f.var('glamt', 0); zlatT = f.var('gphit', 0)
+        ze1T = f.var('e1t', 0) / 1000.
+        ze2T = f.var('e2t', 0) / 1000.
+    kmaskt = np.array(kmaskt, dtype='i1')
+    zlatT = np.asarray(zlatT, dtype=np.float64); zlatF = np.asarray(zlatF, dtype=np.float64)
+    zlonT = np.mod(np.asarray(zlonT, dtype=np.float64), 360.)
+    zlonF = np.mod(np.asarray(zlonF, dtype=np.float64), 360.)
+    zYt, zXt = _project(ctx, zlatT, zlonT)
+    zYf, zXf = _project(ctx, zlatF, zlonF)
+    zResKM = np.sqrt(ze1T * ze1T + ze2T * ze2T).astype(np.float64)
+    return kmaskt, zlatT, zlonT, zYt, zXt, zYf, zXf, zResKM
+
+
+def GetModelUVGrid(fNCmeshmask, ctx):
+    """Reference ncio.py:66-92 -> zYv, zXv, zYu, zXu."""
+    with _Reader(fNCmeshmask) as f:
+        zlonV = f.var('glamv', 0); zlatV = f.var('gphiv', 0)
+        zlonU = f.var('glamu', 0); zlatU = f.var('gphiu', 0)
+    zYv, zXv = _project(ctx, np.asarray(zlatV, dtype=np.float64), np.mod(np.asarray(zlonV, dtype=np.float64), 360.))
+    zYu, zXu = _project(ctx, np.asarray(zlatU, dtype=np.float64), np.mod(np.asarray(zlonU, dtype=np.float64), 360.))
+    return zYv, zXv, zYu, zXu
+
+
+def LoadNCtime(cfile, ltime2d=False):
+    """Reference ncio.py:199-239."""
+    with _Reader(cfile) as f:
+        if not f.has_dim('time') or not f.has_var('time'):
+            raise ValueError(' ERROR [LoadNCtime()]: no `time` dimension/variable found into input file!')
+        Nt = f.dim('time')
+        if f.attr('time', 'units') != tunits_default:
+            raise ValueError(' ERROR [LoadNCtime()]: we expect "' + tunits_default + '" as units for the time record vector')
+        ztime = f.var('time')
+        if ltime2d:
+            if not f.has_var('time_pos'):
+                raise ValueError(' ERROR [LoadNCtime()]: no variable `time_pos` found into input file!')
+            if f.attr('time_pos', 'units') != tunits_default:
+                raise ValueError(' ERROR [LoadNCtime()]: wrong units for the 2D time record array')
+            ztime2d = f.var('time_pos')
+            if ztime2d.shape[0] != Nt:
+                raise ValueError(' ERROR [LoadNCtime()]: array `time_pos` has not the same number of records as `time`!')
+            return Nt, ztime, ztime2d
+    return Nt, ztime
+
+
+def LoadNCdata(cfile, krec=-1, lmask=False, lGetTimePos=False):
+    """Reference ncio.py:243-326: seeding / trajectory file -> ztime, kBIDs, zLatLon, zYX[, zmsk][, ztpos].
+    Longitudes come back in [0,360) (:303); float32 variables are promoted to float64."""
+    need = ['id_buoy', 'latitude', 'longitude', 'y_pos', 'x_pos'] + (['time_pos'] if lGetTimePos else [])
+    with _Reader(cfile) as f:
+        for cd in ('time', 'buoy'):
+            if not f.has_dim(cd):
+                raise ValueError(' ERROR [LoadNCdata()]: no dimensions `' + cd + '` found into input file!')
+        for cv in need:
+            if not f.has_var(cv):
+                raise ValueError(' ERROR [LoadNCdata()]: no variable `' + cv + '` found into input file!')
+        Nt, nP = f.dim('time'), f.dim('buoy')
+        if f.attr('time', 'units') != tunits_default:
+            raise ValueError(' ERROR [LoadNCdata()]: wrong units for the time record vector')
+        idxR = krec if krec >= 0 else slice(None)
+        ztime = f.var('time', idxR)
+        kBIDs = np.zeros(nP, dtype=np.int64)
+        kBIDs[:] = f.var('id_buoy')
+        zlat = np.asarray(f.var('latitude', idxR), dtype=np.float64)
+        zlon = np.mod(np.asarray(f.var('longitude', idxR), dtype=np.float64), 360.)
+        zy = np.asarray(f.var('y_pos', idxR), dtype=np.float64)
+        zx = np.asarray(f.var('x_pos', idxR), dtype=np.float64)
+        zmsk = f.var('mask', idxR) if lmask else None
+        ztpos = f.var('time_pos', idxR) if lGetTimePos else None
+    zLatLon = np.stack([zlat, zlon], axis=-1)
+    zYX = np.stack([zy, zx], axis=-1)
+    out = [ztime, kBIDs, zLatLon, zYX]
+    if lmask:
+        out.append(zmsk)
+    if lGetTimePos:
+        out.append(ztpos)
+    return tuple(out)
+
+
+def SeedFileTimeInfo(fSeedNc, ltime2d=False):
+    """Reference ncio.py:329-352 -> idate0, idateN (rounded to the hour), SeedName, SeedBatch, time_pos or []."""
+    from math import ceil, floor
+    cSeed = path.basename(fSeedNc).replace('SELECTION_', '').replace('.nc', '')
+    cBtch = path.basename(fSeedNc).split('_')[2]
+    if ltime2d:
+        ntr, zt, zt2d = LoadNCtime(fSeedNc, ltime2d=True)
+        idate0, idateN = np.min(zt2d), np.max(zt2d)
+    else:
+        ntr, zt = LoadNCtime(fSeedNc)
+        idate0, idateN = zt[0], zt[ntr - 1]
+        zt2d = []
+    idate0, idateN = int(floor(idate0 / 3600.) * 3600.), int(ceil(idateN / 3600.) * 3600.)
+    return idate0, idateN, cSeed, cBtch, zt2d
+
+
+def ModelFileTimeInfo(fModelNc):
+    """Reference ncio.py:356-384 -> Nt, ztime (i4), idate0, idateN, nconf, nexpr (from the file NAME)."""
+    with _Reader(fModelNc) as f:
+        Nt = f.dim('time_counter')
+        if f.attr('time_counter', 'units') != tunits_default:
+            raise ValueError('ERROR: wrong units for time calendar in file: ' + fModelNc)
+        ztime = np.array(f.var('time_counter'), dtype='i4')
+    idate0, idateN = np.min(ztime), np.max(ztime)
+    vn = path.basename(fModelNc).split('_')
+    zz = vn[1].split('-')
+    nconf = vn[0]
+    if len(zz) == 1:
+        zz = vn[0].split('-')
+        nconf = zz[0]
+    nexpr = zz[1]
+    return Nt, ztime, idate0, idateN, nconf, nexpr
+
+
+class ModelRecords:
+    """Keeps the SI3 file open and hands out the raw (unmasked) slabs of one record
+    (reference si3_part_tracker.py:359,365-374)."""
+
+    def __init__(self, cf_uv):
+        self.f = _Reader(cf_uv)
+
+    def time(self, jrec):
+        return int(self.f.var('time_counter', jrec))
+
+    def fields(self, jrec, names=('u_ice', 'v_ice', 'siconc')):
+        return tuple(self.f.var(n, jrec) for n in names)
+
+    def close(self):
+        self.f.close()
+
+
+def ncSaveCloudBuoys(cf_out, ptime, pIDs, pY, pX, pLat, pLon, mask=[], xtime=[], tunits=tunits_default, fillVal=FillValue,
+                     corigin=None, cauthor='si3_part_tracker.py'):
+    """Reference ncio.py:131-197: dims time (unlimited), buoy; time i4, buoy i4, id_buoy i8, latitude/longitude/
+    y_pos/x_pos f4 (_FillValue -9999, zlib 9), optional mask i1 and time_pos i4; global Origin/About/Author."""
+    (Nt,) = np.shape(ptime)
+    (Nb,) = np.shape(pIDs)
+    for a in (pY, pX, pLat, pLon):
+        if np.shape(a) != (Nt, Nb):
+            raise ValueError('ERROR [ncSaveCloudBuoys]: one of the 2D arrays has a wrong shape!!!')
+    lSaveMask = (np.shape(mask) == (Nt, Nb))
+    lSaveTime = (np.shape(xtime) == (Nt, Nb))
+    os.makedirs(path.dirname(cf_out) or '.', exist_ok=True)
+    about = 'Lagrangian sea-ice drift'
+    author = 'Generated with `' + cauthor + '` of `sitrack` (L. Brodeau, 2023)'
+    if _nc4 is not None:
+        f = _nc4.Dataset(cf_out, 'w', format='NETCDF4')
+        f.createDimension('time', None)
+        f.createDimension('buoy', Nb)
+        v_time = f.createVariable('time', 'i4', ('time',))
+        v_buoy = f.createVariable('buoy', 'i4', ('buoy',))
+        v_bid = f.createVariable('id_buoy', 'i8', ('buoy',))
+        kw = dict(fill_value=fillVal, zlib=True, complevel=9)
+        x_lat = f.createVariable('latitude', 'f4', ('time', 'buoy'), **kw)
+        x_lon = f.createVariable('longitude', 'f4', ('time', 'buoy'), **kw)
+        x_ykm = f.createVariable('y_pos', 'f4', ('time', 'buoy'), **kw)
+        x_xkm = f.createVariable('x_pos', 'f4', ('time', 'buoy'), **kw)
+        if lSaveMask:
+            v_mask = f.createVariable('mask', 'i1', ('time', 'buoy'), zlib=True, complevel=9)
+        if lSaveTime:
+            x_tim = f.createVariable('time_pos', 'i4', ('time', 'buoy'), **kw)
+    else:
+        from scipy.io import netcdf_file
+        f = netcdf_file(cf_out, 'w', version=2)
+        f.createDimension('time', None)
+        f.createDimension('buoy', Nb)
+        v_time = f.createVariable('time', 'i4', ('time',))
+        v_buoy = f.createVariable('buoy', 'i4', ('buoy',))
+        v_bid = f.createVariable('id_buoy', 'f8', ('buoy',))          # NetCDF-3 has no int64
+        v_bid.note = 'int64 IDs stored as float64 (NetCDF-3 fall-back writer)'
+        x_lat = f.createVariable('latitude', 'f4', ('time', 'buoy'))
+        x_lon = f.createVariable('longitude', 'f4', ('time', 'buoy'))
+        x_ykm = f.createVariable('y_pos', 'f4', ('time', 'buoy'))
+        x_xkm = f.createVariable('x_pos', 'f4', ('time', 'buoy'))
+        for v in (x_lat, x_lon, x_ykm, x_xkm):
+            v._FillValue = np.float32(fillVal)
+        if lSaveMask:
+            v_mask = f.createVariable('mask', 'i1', ('time', 'buoy'))
+        if lSaveTime:
+            x_tim = f.createVariable('time_pos', 'i4', ('time', 'buoy'))
+            x_tim._FillValue = np.int32(fillVal)
+    v_time.units = tunits
+    v_bid.units = 'ID of buoy'
+    x_lat.units = 'degrees north'
+    x_lon.units = 'degrees south'
+    x_ykm.units = 'km'
+    x_xkm.units = 'km'
+    if lSaveTime:
+        x_tim.units = tunits
+    v_buoy[:] = np.arange(Nb, dtype='i4')
+    v_bid[:] = np.asarray(pIDs)[:]
+    for jt in range(Nt):
+        v_time[jt] = int(ptime[jt])
+        x_lat[jt, :] = np.asarray(pLat[jt, :], dtype=np.float32)
+        x_lon[jt, :] = np.asarray(pLon[jt, :], dtype=np.float32)
+        x_ykm[jt, :] = np.asarray(pY[jt, :], dtype=np.float32)
+        x_xkm[jt, :] = np.asarray(pX[jt, :], dtype=np.float32)
+        if lSaveMask:
+            v_mask[jt, :] = np.asarray(mask[jt, :], dtype='i1')
+        if lSaveTime:
+            x_tim[jt, :] = np.asarray(xtime[jt, :]).astype('i4')
+    if corigin:
+        f.Origin = corigin
+    f.About = about
+    f.Author = author
+    f.close()
+    return 0

@@ -1,0 +1,202 @@
+"""Driver plumbing: file-name logic, record windows, date helpers on CPU;
+the whole command line end to end on the GPU against an independent oracle-driven run."""
+import os
+
+import numpy as np
+import pytest
+
+from sitrack_amd import driver as drv
+from sitrack_amd import ncio
+from sitrack_amd import synthetic as syn
+
+
+def test_output_name_of_the_reference_readme_demo():
+    # reference README.md:83-97: seeding file, model file, `-e 1997-04-20 -F` -> documented output name
+    cdtbin, csfkm = drv.seed_name_tokens('sitrack_seeding_nemoTsi3_19961215_00_HSS5.nc')
+    assert (cdtbin, csfkm) == ('_idlSeed', '')
+    seed_batch = 'sitrack_seeding_nemoTsi3_19961215_00_HSS5.nc'.split('_')[2]
+    t0 = drv.clock2epoch('1996-12-15_00:00:00')
+    t1 = drv.clock2epoch('1997-04-20')
+    name = ('./nc/NEMO-SI3_NANUK4_BBM23U06_tracking_' + seed_batch + cdtbin + '_' + drv.date_tag(t0) + '_' + drv.date_tag(t1)
+            + csfkm + '.nc')
+    assert name == './nc/NEMO-SI3_NANUK4_BBM23U06_tracking_nemoTsi3_idlSeed_19961215h00_19970420h00.nc'
+
+
+def test_seed_name_tokens_variants():
+    assert drv.seed_name_tokens('sitrack_seeding_sidfex_19961215_00_HSS5.nc') == ('_idlSeed', '')
+    assert drv.seed_name_tokens('sitrack_seeding_nemoTsi3_19961215_00_HSS5_10km.nc') == ('_idlSeed', '_10km')
+    # RGPS-style selection files: ..._dt72_10km.nc  /  ..._dt72.nc
+    assert drv.seed_name_tokens('SELECTION_RGPS_S008_dt72_19970104h00_19970107h00_10km.nc')[1] == '_10km'
+    with pytest.raises((ValueError, IndexError)):
+        drv.seed_name_tokens('whatever_file_name_without_tokens.nc')
+
+
+def test_dates_roundtrip():
+    t = 850608000                                   # the reference fixture's time: 1996-12-15 00:00 UTC
+    assert drv.epoch2clock(t) == '1996-12-15_00:00:00'
+    assert drv.clock2epoch('1996-12-15_00:00:00') == t and drv.clock2epoch('1996-12-15') == t and drv.clock2epoch('19961215') == t
+    assert drv.date_tag(t + 3 * 3600) == '19961215h03'
+
+
+def test_record_windows():
+    base = 850608000
+    vt = (base + 1800 + 3600 * np.arange(24)).astype('i4')
+    kstrt, kstop = 0, 23
+    iTmA, iTmB = vt[kstrt], vt[kstop]
+    zT = np.array([[base, base + 5 * 3600, base + 2 * 3600 + 1800], [vt[-1] + 1800, base + 12 * 3600, vt[-1]]])
+    z1, zL = drv.record_windows(zT, vt, kstrt, kstop, iTmA, iTmB, 3)
+    # hand-evaluated from reference si3_part_tracker.py:289-312 (strict comparisons against record centres +- rdt/2)
+    assert list(z1) == [0, 4, 2]
+    assert list(zL) == [23, 12, 23]
+
+
+def _write_nc3(fname, dims, variables, attrs=None):
+    from scipy.io import netcdf_file
+    f = netcdf_file(fname, 'w', version=2)
+    for d, n in dims.items():
+        f.createDimension(d, n)
+    for name, (typ, dd, data, att) in variables.items():
+        v = f.createVariable(name, typ, dd)
+        v[:] = data
+        for k, val in (att or {}).items():
+            setattr(v, k, val)
+    for k, val in (attrs or {}).items():
+        setattr(f, k, val)
+    f.close()
+
+
+def make_case(tmp, nrec=14, nP=300, two_d_time=False):
+    """Synthetic NANUK-like inputs as NetCDF-3 files: mesh_mask, icemod (hourly), seeding file."""
+    from oracle import oracle as orc
+    Nj, Ni, dkm = 60, 70, 10.0
+    g = syn.make_grid(Nj, Ni, dkm=dkm, warp=1.0)
+    for k in ("Yt", "Yu", "Yv", "Yf"):
+        g[k] = g[k] - 250.
+    for k in ("Xt", "Xu", "Xv", "Xf"):
+        g[k] = g[k] + 150.
+    ll = {p: orc.CartNPSkm2Geo1D(np.stack([g["Y" + p].ravel(), g["X" + p].ravel()], axis=1)) for p in "tufv"}
+    tmask = g["tmask"].copy(); tmask[25:30, 40:46] = 0
+    mm = os.path.join(tmp, "mesh_mask_TEST4.nc")
+    var = {"tmask": ('i1', ('t', 'z', 'y', 'x'), tmask[None, None], None),
+           "e1t": ('f8', ('t', 'y', 'x'), np.full((1, Nj, Ni), dkm * 1000.), None),
+           "e2t": ('f8', ('t', 'y', 'x'), np.full((1, Nj, Ni), dkm * 1000.), None)}
+    for p in "tufv":
+        var["glam" + p] = ('f8', ('t', 'y', 'x'), ll[p][:, 1].reshape(1, Nj, Ni), None)
+        var["gphi" + p] = ('f8', ('t', 'y', 'x'), ll[p][:, 0].reshape(1, Nj, Ni), None)
+    _write_nc3(mm, {"t": 1, "z": 1, "y": Nj, "x": Ni}, var)
+    base = 850608000
+    u, v, sic = syn.make_fields(g, K=nrec, seed=77, umax=0.9, drift=0.3, ripple=0.1)
+    sic[:, 10:16, 12:30] = 0.03
+    tc = (base + 1800 + 3600 * np.arange(nrec)).astype('i4')
+    si3 = os.path.join(tmp, "TEST4-EXP01_1h_19961215_19961216_icemod.nc")
+    _write_nc3(si3, {"time_counter": None, "y": Nj, "x": Ni},
+               {"time_counter": ('i4', ('time_counter',), tc, {"units": ncio.tunits_default}),
+                "siconc": ('f4', ('time_counter', 'y', 'x'), sic, None),
+                "u_ice": ('f4', ('time_counter', 'y', 'x'), u, None),
+                "v_ice": ('f4', ('time_counter', 'y', 'x'), v, None)})
+    rng = np.random.default_rng(5)
+    yx = np.stack([rng.uniform(g["Yt"].min() + 30, g["Yt"].max() - 30, nP), rng.uniform(g["Xt"].min() + 30, g["Xt"].max() - 30, nP)], axis=1)
+    sll = orc.CartNPSkm2Geo1D(yx)
+    ids = (300534062025510 + 7 * np.arange(nP)).astype(np.int64)
+    seed = os.path.join(tmp, "sitrack_seeding_nemoTsi3_19961215_00_HSS5.nc")
+    sv = {"time": ('i4', ('time',), np.array([base], dtype='i4'), {"units": ncio.tunits_default}),
+          "buoy": ('i4', ('buoy',), np.arange(nP, dtype='i4'), None),
+          "id_buoy": ('f8', ('buoy',), ids.astype(np.float64), {"units": "ID of buoy"}),
+          "latitude": ('f4', ('time', 'buoy'), sll[None, :, 0].astype('f4'), None),
+          "longitude": ('f4', ('time', 'buoy'), sll[None, :, 1].astype('f4'), None),
+          "y_pos": ('f4', ('time', 'buoy'), yx[None, :, 0].astype('f4'), None),
+          "x_pos": ('f4', ('time', 'buoy'), yx[None, :, 1].astype('f4'), None)}
+    if two_d_time:
+        tp = np.stack([np.full(nP, base), np.full(nP, tc[-1] + 1800)]).astype('i4')
+        tp[0, ::7] = base + 4 * 3600                  # some buoys start later
+        tp[1, ::5] = base + 9 * 3600                  # some stop earlier
+        sv["time"] = ('i4', ('time',), np.array([base, tc[-1] + 1800], dtype='i4'), {"units": ncio.tunits_default})
+        for k in ("latitude", "longitude", "y_pos", "x_pos"):
+            sv[k] = (sv[k][0], sv[k][1], np.repeat(sv[k][2], 2, axis=0), None)
+        sv["time_pos"] = ('i4', ('time', 'buoy'), tp, {"units": ncio.tunits_default})
+    _write_nc3(seed, {"time": None, "buoy": nP}, sv)
+    return dict(g=g, ll=ll, tmask=tmask, u=u, v=v, sic=sic, tc=tc, yx=yx, sll=sll, ids=ids, mm=mm, si3=si3, seed=seed, base=base)
+
+
+def oracle_run(c, two_d_time, rdt=3600.):
+    """Independent restatement of the whole driver with the CPU oracle (same file contents)."""
+    from oracle import oracle as orc
+    g = c["g"]
+    Nj, Ni = g["Nj"], g["Ni"]
+    grid = {}
+    for p, k in (("f", "f"), ("u", "u"), ("v", "v"), ("t", "t")):
+        lat = c["ll"][p][:, 0]; lon = np.mod(c["ll"][p][:, 1], 360.)
+        yx = orc.Geo2CartNPSkm1D(np.stack([lat, lon], axis=1))
+        grid["Y" + k] = np.ascontiguousarray(yx[:, 0].reshape(Nj, Ni)); grid["X" + k] = np.ascontiguousarray(yx[:, 1].reshape(Nj, Ni))
+    grid["tmask"] = c["tmask"]
+    latT = c["ll"]["t"][:, 0].reshape(Nj, Ni); lonT = np.mod(c["ll"]["t"][:, 1], 360.).reshape(Nj, Ni)
+    pSG = np.stack([c["sll"][:, 0].astype('f4').astype('f8'), np.mod(c["sll"][:, 1].astype('f4').astype('f8'), 360.)], axis=1)
+    pSC = c["yx"].astype('f4').astype('f8')
+    res = np.full((Nj, Ni), np.sqrt(2.) * 10.0)
+    tc = c["tc"]
+    kstrt, Nt = 0, len(tc)
+    nP, oSG, oSC, oIDs, ojiT, overt, keep = orc.SeedInit(c["ids"], pSG, pSC, np.ascontiguousarray(latT), np.ascontiguousarray(lonT),
+                                                          grid["Yf"], grid["Xf"], res, c["tmask"], c["sic"][kstrt].astype('f8'))
+    z1 = np.zeros(nP, dtype=int) + kstrt; zL = np.zeros(nP, dtype=int) + (kstrt + Nt - 1)
+    if two_d_time:
+        base = c["base"]
+        tp0 = np.full(len(c["ids"]), base); tp0[::7] = base + 4 * 3600
+        tp1 = np.full(len(c["ids"]), tc[-1] + 1800); tp1[::5] = base + 9 * 3600
+        z1, zL = drv.record_windows(np.stack([tp0, tp1]), tc, kstrt, kstrt + Nt - 1, tc[0], tc[-1], len(c["ids"]))
+        z1, zL = z1[keep], zL[keep]
+    trk = orc.Tracker(grid, oSC, ojiT, rec_first=z1, rec_last=zL)
+    pos = np.zeros((Nt + 1, nP, 2)) + -9999.; msk = np.zeros((Nt + 1, nP), dtype='i1')
+    pos[z1 - kstrt, np.arange(nP)] = oSC; msk[z1 - kstrt, np.arange(nP)] = 1
+    for jt in range(Nt):
+        pn, mn = trk.step(jt + kstrt, c["u"][jt].astype('f8'), c["v"][jt].astype('f8'), c["sic"][jt].astype('f8'))
+        pos[jt + 1, mn == 1] = pn[mn == 1]; msk[jt + 1, mn == 1] = 1
+    return dict(nP=nP, ids=oIDs, pos=pos, msk=msk, jiT=trk.jiT, alive=trk.alive, z1=z1, zL=zL, seedG=oSG)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("two_d_time", [False, True])
+def test_cli_end_to_end_vs_oracle(tmp_path, monkeypatch, two_d_time):
+    from oracle import oracle as orc
+    monkeypatch.chdir(tmp_path)
+    c = make_case(str(tmp_path), two_d_time=two_d_time)
+    argv = ["-i", c["si3"], "-m", c["mm"], "-s", c["seed"], "-N", "TEST4"] + ([] if two_d_time else ["-F"])
+    out = drv.main(argv)
+    ref = oracle_run(c, two_d_time)
+    assert out["nP"] == ref["nP"] and np.array_equal(out["IDs"], ref["ids"])
+    assert np.array_equal(out["vJIt"], ref["jiT"]) and np.array_equal(out["iAlive"], ref["alive"])
+    assert os.path.exists("./seed/Initialized_buoys_sitrack_seeding_nemoTsi3_19961215_00_HSS5_TEST4.npz")
+    with np.load("./seed/Initialized_buoys_sitrack_seeding_nemoTsi3_19961215_00_HSS5_TEST4.npz") as z:
+        assert sorted(z.files) == sorted(['nP', 'xPosG0', 'xPosC0', 'IDs', 'vJIt', 'VRTCS', 'idxKeep'])
+    Nt = len(c["tc"])
+    if not two_d_time:
+        f_full, f_12 = out["files"]
+        assert f_full == './nc/NEMO-SI3_TEST4_EXP01_tracking_nemoTsi3_idlSeed_19961215h00_19961215h14.nc'
+        assert f_12 == './nc/NEMO-SI3_TEST4_EXP01_tracking12_nemoTsi3_idlSeed_19961215h00_19961215h14.nc'
+        t, ids, llo, yxo, mko = ncio.LoadNCdata(f_full, krec=-1, lmask=True)
+        assert np.array_equal(ids, ref["ids"]) and t.shape == (Nt + 1,) and t[0] == c["base"] and t[-1] == c["base"] + Nt * 3600
+        assert np.array_equal(mko, ref["msk"])
+        assert np.array_equal(yxo.astype('f4'), ref["pos"].astype('f4'))         # y_pos/x_pos are stored as f4
+        # lat/lon of records >= 1: inverse projection (1e-5 relative is the bar; device libm vs glibc ~1e-12)
+        want = orc.CartNPSkm2Geo1D(ref["pos"][1:].reshape(-1, 2)).reshape(Nt, -1, 2)
+        got = llo[1:].copy(); want[..., 1] = np.mod(want[..., 1], 360.)           # LoadNCdata returns lon in [0,360)
+        assert np.allclose(got, want.astype('f4').astype('f8'), rtol=1e-6, atol=1e-4)
+        # record 0 keeps the seeding file's own coordinates
+        assert np.allclose(llo[0], ref["seedG"], rtol=0, atol=1e-4)
+        t2, _, _, yx2, mk2 = ncio.LoadNCdata(f_12, krec=-1, lmask=True)
+        assert np.array_equal(yx2[0].astype('f4'), ref["pos"][0].astype('f4')) and np.array_equal(yx2[1].astype('f4'), ref["pos"][Nt].astype('f4'))
+        assert np.array_equal(mk2[1], ref["msk"][Nt])
+    else:
+        (f_12,) = out["files"]
+        assert '_tracking12_nemoTsi3_idlSeed_' in f_12
+        t2, _, _, yx2, mk2, tp2 = ncio.LoadNCdata(f_12, krec=-1, lmask=True, lGetTimePos=True)
+        nP = ref["nP"]
+        kN = ref["zL"] + 1
+        k0 = ref["z1"]
+        assert np.array_equal(yx2[0].astype('f4'), ref["pos"][k0, np.arange(nP)].astype('f4'))
+        assert np.array_equal(yx2[1].astype('f4'), ref["pos"][kN, np.arange(nP)].astype('f4'))
+        assert np.array_equal(mk2[1], ref["msk"][kN, np.arange(nP)])
+        want_t1 = np.where(ref["msk"][kN, np.arange(nP)] == 1, c["tc"][ref["zL"]] - 1800 + 3600, -9999)
+        assert np.array_equal(tp2[1], want_t1) and np.array_equal(tp2[0], c["tc"][k0] - 1800)
+    # second run hits the seed cache and reproduces the same result
+    out2 = drv.main(argv)
+    assert np.array_equal(out2["vJIt"], out["vJIt"]) and np.array_equal(out2["iAlive"], out["iAlive"])
