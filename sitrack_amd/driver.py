@@ -157,6 +157,11 @@ def main(argv=None):
     zLstModelRec = np.zeros(nP, dtype=int) + kstop
     if lUse2DTime:
         zTpos = np.asarray(zTpos)
+        if zTpos.shape != (2, nP) and zTpos.ndim == 2 and zTpos.shape[1] > nP and len(idxK) == nP:
+            # SeedInit cancelled buoys: keep the time positions of the survivors.  (The reference has this line
+            # commented out, si3_part_tracker.py:250, and then stops on the shape check of :269-272.)
+            print(' *** adjusting `zTpos` to the %d buoys kept by SeedInit' % nP)
+            zTpos = zTpos[:, idxK]
         if zTpos.shape != (2, nP):
             raise ValueError('wrong shape for the 2D time array `zTpos`: %s vs nP=%d' % (zTpos.shape, nP))
         z1stModelRec, zLstModelRec = record_windows(zTpos, ztime_model, kstrt, kstop, iTmA, iTmB, nP)
