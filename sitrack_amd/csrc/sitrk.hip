@@ -190,6 +190,11 @@ SITRK_API int sitrk_set_tuning(sitrk_t *h, const char *knob, int value)
     int bit = 0;
     if (!strcmp(knob, "xcd_remap")) bit = TUNE_XCD_REMAP;
     else if (!strcmp(knob, "nt_state")) bit = TUNE_NT_STATE;
+    else if (!strcmp(knob, "fuse")) {                // records per launch in sitrk_run (1..8)
+        if (value < 1 || value > kMaxFuse) return fail(h, SITRK_EINVAL, "sitrk_set_tuning: fuse must be 1..%d", kMaxFuse);
+        h->fuse = value;
+        return SITRK_OK;
+    }
     else if (!strcmp(knob, "sort_tile")) {           // value = tile_j * 256 + tile_i, 0 = row-major
         const int tj = value >> 8, ti = value & 255;
         if (value != 0 && (tj < 1 || ti < 1)) return fail(h, SITRK_EINVAL, "sitrk_set_tuning: sort_tile = tile_j*256 + tile_i");
@@ -440,15 +445,64 @@ SITRK_API int sitrk_step(sitrk_t *h, int slot, int jrec)
     return SITRK_OK;
 }
 
+template <typename FT>
+static void launch_run(sitrk_ctx *h, const RunArgs &ra)
+{
+    dim3 grid(nblocks(ra.s.nP)), block(kBlock);
+    if (h->uv_strategy == 1) {
+        if (h->windowed) hipLaunchKernelGGL((advect_run_kernel<FT, 1, true>), grid, block, 0, h->stream, ra);
+        else hipLaunchKernelGGL((advect_run_kernel<FT, 1, false>), grid, block, 0, h->stream, ra);
+    } else {
+        if (h->windowed) hipLaunchKernelGGL((advect_run_kernel<FT, 0, true>), grid, block, 0, h->stream, ra);
+        else hipLaunchKernelGGL((advect_run_kernel<FT, 0, false>), grid, block, 0, h->stream, ra);
+    }
+}
+
 SITRK_API int sitrk_run(sitrk_t *h, int slot0, int jrec0, int nsteps)
 {
     NEED(h, "null handle");
     NEED(nsteps >= 0, "sitrk_run: nsteps must be >= 0");
     NEED(h->nslots > 0, "sitrk_run: call sitrk_alloc_records first");
     NEED(slot0 >= 0 && slot0 < h->nslots, "sitrk_run: slot0 out of range");
-    for (int k = 0; k < nsteps; k++) {
-        int rc = sitrk_step(h, (slot0 + k) % h->nslots, jrec0 + k);
-        if (rc) return rc;
+    NEED(h->st[0].pos, "sitrk_run: call sitrk_set_buoys first");
+    if (h->nP == 0) return SITRK_OK;
+    const int fuse = std::max(1, std::min(std::min(h->fuse, kMaxFuse), h->nslots));
+    const size_t n = (size_t)h->Nj * h->Ni, es = elem_size(h->dtype);
+    int k = 0;
+    while (k < nsteps) {
+        if (h->resort_every > 0 && h->steps_since_sort >= h->resort_every) {
+            int rc = sitrk_sort_buoys(h);
+            if (rc) return rc;
+        }
+        int m = std::min(fuse, nsteps - k);
+        if (h->resort_every > 0) m = std::min(m, h->resort_every - h->steps_since_sort);
+        if (m <= 1) {
+            int rc = sitrk_step(h, (slot0 + k) % h->nslots, jrec0 + k);
+            if (rc) return rc;
+            k += 1;
+            continue;
+        }
+        // m consecutive records, all resident in distinct slots, in one launch
+        BuoyState &s = h->st[h->cur];
+        RunArgs ra;
+        ra.s.nP = h->nP; ra.s.tune = h->tune; ra.s.Nj = h->Nj; ra.s.Ni = h->Ni; ra.s.jrec = jrec0 + k;
+        ra.s.rdt = h->rdt; ra.s.rmin_conc = h->rmin_conc; ra.s.geo = h->geo; ra.s.kill = nullptr; ra.s.u = ra.s.v = nullptr;
+        ra.s.pos = s.pos; ra.s.cell = s.cell; ra.s.kill_rec = s.kill_rec; ra.s.first = s.first; ra.s.last = s.last;
+        ra.nrec = m;
+        for (int r = 0; r < m; r++) {
+            const int slot = (slot0 + k + r) % h->nslots;
+            if (h->slot_dirty[slot]) {
+                int rc = derive_mask(h, slot);
+                if (rc) return rc;
+            }
+            const char *slab = slab_of(h, slot);
+            ra.u[r] = slab; ra.v[r] = slab + n * es; ra.kill[r] = h->kill + (size_t)slot * n;
+        }
+        if (h->dtype == SITRK_F64) launch_run<double>(h, ra);
+        else launch_run<float>(h, ra);
+        HIPCHK(hipGetLastError());
+        h->steps_since_sort += m;
+        k += m;
     }
     return SITRK_OK;
 }

@@ -226,6 +226,92 @@ __global__ __launch_bounds__(kBlock) void advect_step_kernel(StepArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------
+// Several consecutive records in ONE launch (sitrk_run).  Buoys never interact, so the loop nest
+// "for record: for buoy" of the reference can be interchanged for the records that are resident
+// together: each lane keeps its buoy's position and cell in registers across up to kMaxFuse
+// records, the geometry lines it needs stay in L2 between iterations (a buoy moves < 1 cell per
+// record), and the once-per-record position/cell streams are read and written once per launch.
+// Per buoy the sequence of operations is exactly the one of advect_step_kernel -> identical results.
+// ---------------------------------------------------------------------------
+static constexpr int kMaxFuse = 8;
+
+struct RunArgs {
+    StepArgs s;                         // s.u/s.v/s.kill unused; s.jrec = first record
+    int nrec;
+    const void *u[kMaxFuse], *v[kMaxFuse];
+    const int8_t *kill[kMaxFuse];
+};
+
+template <typename FT, int UVS, bool WINDOW>
+__global__ __launch_bounds__(kBlock) void advect_run_kernel(RunArgs ra)
+{
+    const StepArgs &a = ra.s;
+    const unsigned blk = (a.tune & TUNE_XCD_REMAP) ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    int64_t p = (int64_t)blk * kBlock + threadIdx.x;
+    if (p >= a.nP) return;
+    const bool nt = (a.tune & TUNE_NT_STATE) != 0;
+    int32_t c = nt ? __builtin_nontemporal_load(&a.cell[p]) : a.cell[p];
+    if (c < 0) return;
+    int first = 0, last = 0x7fffffff;
+    if (WINDOW) { first = a.first[p]; last = a.last[p]; }
+    const int Ni = a.Ni, Nj = a.Nj;
+    pt P = nt ? load_pt_nt(&a.pos[p]) : a.pos[p];
+    const int32_t c0 = c;
+    bool moved = false;
+#pragma unroll 1
+    for (int r = 0; r < ra.nrec; r++) {
+        const int jrec = a.jrec + r;
+        if (WINDOW) {
+            if (jrec < first) continue;
+            if (jrec > last) break;
+        }
+        const int jT = cell_j(c), iT = cell_i(c);
+        const size_t k = (size_t)jT * Ni + iT;
+        const FT *__restrict__ u = (const FT *)ra.u[r];
+        const FT *__restrict__ v = (const FT *)ra.v[r];
+        const CellGeo g11 = a.geo[k];
+        const pt F10 = a.geo[k - 1].f;
+        const pt F01 = a.geo[k - Ni].f;
+        const pt F00 = a.geo[k - Ni - 1].f;
+        double zU, zV;
+        if (UVS == 0) {
+            zU = 0.5 * ((double)u[k] + (double)u[k - 1]);
+            zV = 0.5 * ((double)v[k] + (double)v[k - Ni]);
+        } else {
+            const pt U10 = a.geo[k - 1].u;
+            const pt V01 = a.geo[k - Ni].v;
+            const double u1 = (double)u[k], u0 = (double)u[k - 1];
+            const double v1 = (double)v[k], v0 = (double)v[k - Ni];
+            const bool llum1 = intersect2seg(P, g11.f, V01, g11.v);
+            const bool llvm1 = intersect2seg(P, g11.f, U10, g11.u);
+            zU = llum1 ? u0 : u1;
+            zV = llvm1 ? v0 : v1;
+        }
+        const double dx = zU * a.rdt;
+        const double dy = zV * a.rdt;
+        pt Pn;
+        Pn.x = P.x + dx / 1000.;
+        Pn.y = P.y + dy / 1000.;
+        moved = true;
+        if (!inside_quad(Pn.y, Pn.x, F00, F01, g11.f, F10)) {
+            bool killed;
+            c = resolve_crossing(P, Pn, F00, F01, g11.f, F10, jT, iT, Nj, Ni, a.geo, ra.kill[r], killed);
+            if (killed) {
+                a.kill_rec[p] = jrec;
+                P = Pn;
+                break;                                   // dead buoys never step again
+            }
+        }
+        P = Pn;
+    }
+    if (moved) {
+        if (nt) store_pt_nt(&a.pos[p], P);
+        else a.pos[p] = P;
+    }
+    if (c != c0) a.cell[p] = c;
+}
+
 #ifdef SITRK_DIAG
 // ---------------------------------------------------------------------------
 // ABLATION KERNELS (diagnostic builds only, `make DIAG=1`; results are WRONG by design).

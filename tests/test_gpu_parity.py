@@ -99,6 +99,77 @@ def test_random_cloud_vs_oracle(warp, field_dtype):
         trk.close()
 
 
+@pytest.mark.parametrize("windowed", [False, True])
+def test_fused_run_equals_stepping(windowed):
+    """sitrk_run with several records per launch == one launch per record == the oracle."""
+    grid = syn.make_grid(120, 128, dkm=4.0, warp=1.0)
+    K, Nt = 7, 37
+    u, v, sic = syn.make_fields(grid, K=K, seed=13, umax=0.9, drift=0.3, ripple=0.1)
+    tmask = grid["tmask"].copy(); tmask[50:56, 60:70] = 0
+    sic[:, 20:30, 20:50] = 0.02
+    _, yx = syn.make_buoys(grid, 20000, seed=4, frac=0.75)
+    rng = np.random.default_rng(1)
+    res = []
+    for fuse in (1, 3, 8):
+        trk = make_tracker(grid, tmask, K)
+        found, ji, _ = sit.FindContainingCell(yx, syn.nearest_t_plane(grid, yx), ctx=trk.ctx)
+        n = int(found.sum())
+        first = (2 + rng.integers(0, 9, n)) if windowed else None
+        last = (2 + Nt - 1 - rng.integers(0, 9, n)) if windowed else None
+        rng = np.random.default_rng(1)                      # same windows for every variant
+        trk.set_buoys(yx[found], ji[found], first, last)
+        trk.ctx.set_tuning(fuse=fuse)
+        trk.ctx.set_resort(11)
+        for k in range(K):
+            trk.load_record(k, u[k], v[k], sic[k])
+        trk.ctx.run(2 % K, 2, Nt)
+        res.append(trk.state())
+        trk.close()
+    for r in res[1:]:
+        for key in ("yx", "vJIt", "iAlive", "kill_rec"):
+            assert np.array_equal(r[key], res[0][key]), key
+    g2 = dict(grid); g2["tmask"] = tmask
+    ref = orc.Tracker(g2, yx[found], ji[found], rec_first=first, rec_last=last, nthreads=8)
+    for s in range(Nt):
+        ref.step(2 + s, u[(2 + s) % K], v[(2 + s) % K], sic[(2 + s) % K], want_out=False)
+    assert np.array_equal(res[0]["yx"], ref.pos) and np.array_equal(res[0]["vJIt"], ref.jiT)
+    assert np.array_equal(res[0]["iAlive"], ref.alive)
+    assert 0 < ref.alive.sum() < len(ref.alive)
+
+
+def test_rim_cells_and_negative_index_wrap():
+    """Buoys hosted by row/column 1 (possible after FindContainingCell moved them off the nearest T-point):
+    NewHostCell then reads F[jT-2] = F[-1], which numpy wraps to the last row (reference tracking.py:219,240-242);
+    leaving towards row 0 kills them (Survive rim test)."""
+    Nj, Ni = 24, 26
+    grid = syn.make_grid(Nj, Ni, dkm=4.0, warp=1.0)
+    tmask = np.ones((Nj, Ni), dtype=np.int8)
+    u = np.full((1, Nj, Ni), -0.55, dtype=np.float32); v = np.full((1, Nj, Ni), -0.7, dtype=np.float32)
+    u[0, :, ::3] = 0.4; v[0, ::4, :] = 0.3
+    sic = np.ones((1, Nj, Ni), dtype=np.float32)
+    ji = np.array([[1, i] for i in range(1, Ni - 1)] + [[j, 1] for j in range(2, Nj - 1)] + [[Nj - 2, i] for i in range(2, Ni - 1)]
+                  + [[j, Ni - 2] for j in range(2, Nj - 2)], dtype=np.int64)
+    yx = np.stack([grid["Yt"][ji[:, 0], ji[:, 1]], grid["Xt"][ji[:, 0], ji[:, 1]]], axis=1)
+    ok = np.array([orc.IsInsideQuadrangle(yx[b, 0], yx[b, 1], np.array(
+        [[grid["Yf"][j - 1, i - 1], grid["Xf"][j - 1, i - 1]], [grid["Yf"][j - 1, i], grid["Xf"][j - 1, i]],
+         [grid["Yf"][j, i], grid["Xf"][j, i]], [grid["Yf"][j, i - 1], grid["Xf"][j, i - 1]]])) for b, (j, i) in enumerate(ji)])
+    yx, ji = yx[ok], ji[ok]
+    trk = make_tracker(grid, tmask, 1)
+    trk.set_buoys(yx, ji)
+    trk.load_record(0, u[0], v[0], sic[0])
+    g2 = dict(grid); g2["tmask"] = tmask
+    ref = orc.Tracker(g2, yx, ji)
+    for jrec in range(6):
+        trk.step(jrec, 0)
+        pn, mn = trk.record(jrec)
+        rp, rm = ref.step(jrec, u[0], v[0], sic[0])
+        assert np.array_equal(mn, rm) and np.array_equal(pn, rp), jrec
+    st = trk.state()
+    assert np.array_equal(st["vJIt"], ref.jiT) and np.array_equal(st["iAlive"], ref.alive)
+    assert (ref.alive == 0).sum() > 10 and ref.jiT.min() == 0
+    trk.close()
+
+
 def test_run_many_steps_equals_stepping(ctx):
     grid = syn.make_grid(96, 96, dkm=4.0, warp=1.0)
     u, v, sic = syn.make_fields(grid, K=3, seed=3, umax=0.6, drift=0.2)

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--knobs", default="xcd_remap,nt_state")
     ap.add_argument("--tiles", default="", help="comma list of tile_jxtile_i sort orders to add as variants, e.g. 8x32,16x16")
+    ap.add_argument("--fuse", default="", help="comma list of records-per-launch values to add as variants, e.g. 2,4,8")
     ap.add_argument("--base", default="", help="knob=value,... applied to every variant")
     ap.add_argument("--singles", default="", help="extra variants, one knob each (e.g. diag_memonly,diag_nocross); no result check")
     a = ap.parse_args()
@@ -49,7 +50,9 @@ def main():
     for t in [t for t in a.tiles.split(",") if t]:
         tj, ti = (int(x) for x in t.split("x"))
         variants.append(dict({k: 0 for k in allk}, sort_tile=tj * 256 + ti))
-    variants = [dict(v, **base) for v in variants]
+    for fz in [int(x) for x in a.fuse.split(",") if x]:
+        variants.append(dict({k: 0 for k in allk}, sort_tile=8 * 256 + 16, fuse=fz))
+    variants = [dict(dict(fuse=1), **dict(v, **base)) for v in variants]
     times = {i: [] for i in range(len(variants))}
     ref = None
     for rnd in range(a.rounds):
