@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--check", action="store_true", help="verify a subsample against the oracle after the run")
+    ap.add_argument("--fuse", type=int, default=8,
+                    help="resident records advanced per launch by sitrk_run (loop interchange; 1 = one launch per record)")
     ap.add_argument("--regime", default="resident", choices=["resident", "e2e"],
                     help="resident: records live in HBM (the metric). e2e: every step's record is uploaded from pinned host "
                          "memory on rank 0 (+ RCCL broadcast), double-buffered against the stepping; reported for context only")
@@ -155,7 +157,10 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    per_record = None
     if a.regime == "resident":
+        fuse = max(1, min(a.fuse, K, 8))
+        ctx.set_tuning(fuse=fuse)
         ctx.run(0, 0, a.warmup)
         barrier()
         ctx.timer_start()
@@ -164,7 +169,20 @@ def main():
         ev_ms = ctx.timer_stop()
         barrier()
         dt = time.perf_counter() - t0
+        if fuse > 1:
+            # for reference: the same K steps with one launch per record (the HBM-bound form of the kernel)
+            ctx.set_tuning(fuse=1)
+            s1 = a.warmup + a.steps
+            barrier()
+            ctx.timer_start()
+            t1 = time.perf_counter()
+            ctx.run(s1 % K, s1, a.steps)
+            ev1_ms = ctx.timer_stop()
+            barrier()
+            per_record = (time.perf_counter() - t1, ev1_ms)
+            ctx.set_tuning(fuse=fuse)
     else:
+        fuse = 1
         # end-to-end: record s goes pinned host -> slot s%2 on a copy stream (rank 0), is broadcast, and is
         # consumed by step s on the compute stream; delivery of record s+1 overlaps step s.
         assert K >= 2
@@ -221,31 +239,38 @@ def main():
         from oracle import oracle as orc
         nS = 20000
         ref = orc.Tracker(grid, yx[:nS], ji[:nS], uv_strategy=a.uv_strategy, nthreads=8)
-        for s in range(a.warmup + a.steps):
+        for s in range((a.warmup + a.steps) if per_record is None else (a.warmup + 2 * a.steps)):
             k = s % K
             ref.step(s, u[k].astype(np.float64), v[k].astype(np.float64), sic[k].astype(np.float64), want_out=False)
         st = ctx.fetch()
         assert np.array_equal(st["yx"][:nS], ref.pos) and np.array_equal(st["jiT"][:nS], ref.jiT)
         assert np.array_equal(st["alive"][:nS], ref.alive)
-        print("check OK: first %d buoys bit-exact vs oracle after %d steps" % (nS, a.warmup + a.steps), file=sys.stderr)
+        print("check OK: first %d buoys bit-exact vs oracle after %d steps" % (nS, s + 1), file=sys.stderr)
 
     if rank == 0:
         total = float(nP) * world * a.steps
-        step_s = (ev_ms / 1e3) / a.steps                     # avg launch duration, HIP events, library stream
+        step_s = (ev_ms / 1e3) / a.steps                     # avg time per record, HIP events, library stream
+        nlaunch = (a.steps + fuse - 1) // fuse
         # cells whose record a step needs: the union of every buoy's (j,i),(j,i-1),(j-1,i),(j-1,i-1)
         keys = ji[:, 0].astype(np.int64) * Ni + ji[:, 1]
         need = np.zeros(Nj * Ni, dtype=bool)
         for off in (0, 1, Ni, Ni + 1):
             need[keys - off] = True
         n_cells = int(need.sum())
-        A = 50.0 * nP + 56.0 * n_cells                       # algorithmic bytes per step per GPU
+        A1 = 50.0 * nP + 56.0 * n_cells                      # algorithmic bytes of ONE record per GPU
         A_survey = 50.0 * nP + 56.0 * Nj * Ni                # SURVEY 8d closed form (every cell of the grid)
-        achieved = A / step_s / 1e9
-        traffic = None
+        # a launch that advances `fuse` records reads/writes the 50 B of state and the 48 B of cell geometry once,
+        # and the 8 B of u,v once per record
+        A = 50.0 * nP + 48.0 * n_cells + 8.0 * n_cells * fuse
+        launch_s = (ev_ms / 1e3) / nlaunch
+        achieved = A / launch_s / 1e9
+        traffic = traffic_fused = None
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tj):
             try:
-                traffic = json.load(open(tj)).get(a.config, {}).get("hbm_bytes_per_launch")
+                tjd = json.load(open(tj))
+                traffic = tjd.get(a.config, {}).get("hbm_bytes_per_launch")
+                traffic_fused = tjd.get(a.config + "_fused", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
@@ -256,13 +281,27 @@ def main():
             "config": {"workload": label, "grid": [Nj, Ni], "buoys_per_gpu": nP, "buoys_total": nP * world,
                        "records_resident": K, "record_dtype": "f32", "uv_strategy": a.uv_strategy,
                        "sorted": not a.no_sort, "resort_every": 0 if a.no_sort else resort, "regime": a.regime,
+                       "records_per_launch": fuse,
                        "partition": "buoy-range x%d" % world, "alive_after": nalive},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": A, "cells_needed": n_cells, "kernel": "advect_step_kernel",
-                         "avg_launch_ms": 1e3 * step_s,
-                         "survey_formula_bytes_per_launch": A_survey, "survey_formula_frac": A_survey / step_s / 1e9 / HBM_PEAK_GBS},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_fused if fuse > 1 else traffic,
+                         "algorithmic_bytes_per_launch": A, "cells_needed": n_cells,
+                         "kernel": "advect_run_kernel" if fuse > 1 else "advect_step_kernel", "records_per_launch": fuse,
+                         "avg_launch_ms": 1e3 * launch_s,
+                         "note": ("%d records per launch: state and geometry are read once per launch, so the kernel is "
+                                  "fp64-issue bound, not HBM bound; see per_record_launch for the HBM-bound form" % fuse)
+                         if fuse > 1 else "one record per launch",
+                         "survey_formula_bytes_per_record": A_survey,
+                         "survey_formula_frac_per_record": A_survey / step_s / 1e9 / HBM_PEAK_GBS},
         }
+        if per_record is not None:
+            dt1, ev1 = per_record
+            s1 = (ev1 / 1e3) / a.steps
+            line["per_record_launch"] = {
+                "value": total / dt1, "ms_per_step": 1e3 * dt1 / a.steps, "kernel": "advect_step_kernel",
+                "roofline": {"bound": "hbm", "achieved": A1 / s1 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": A1 / s1 / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": A1,
+                             "avg_launch_ms": 1e3 * s1}}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(grid, u, v, sic, yx, ji, a.cpu_seconds, a.uv_strategy)
         print(json.dumps(line))

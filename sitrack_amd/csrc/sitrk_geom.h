@@ -41,9 +41,10 @@ __device__ __forceinline__ bool intersect2seg(pt A, pt B, pt C, pt D)
 // `xints` is carried between visits when the edge is horizontal (:63,71-73)
 __device__ __forceinline__ void ray_edge(double y, double x, pt z1, pt z2, double &xints, bool &inside)
 {
-    double ymin = (z2.y < z1.y) ? z2.y : z1.y;          // Python min(z1y,z2y)
-    double ymax = (z2.y > z1.y) ? z2.y : z1.y;          // Python max(z1y,z2y)
-    double xmax = (z2.x > z1.x) ? z2.x : z1.x;
+    // Python min()/max() of two finite numbers; only compared against, so the sign of a zero does not matter
+    double ymin = fmin(z1.y, z2.y);
+    double ymax = fmax(z1.y, z2.y);
+    double xmax = fmax(z1.x, z2.x);
     if ((y > ymin) & (y <= ymax) & (x <= xmax)) {
         if (z1.y != z2.y) xints = (y - z1.y) * (z2.x - z1.x) / (z2.y - z1.y) + z1.x;
         if ((z1.x == z2.x) | (x <= xints)) inside = !inside;

@@ -169,7 +169,7 @@ struct StepArgs {
 //   WINDOW : per-buoy first/last model record (2-D time mode, :264-318,380)
 // ---------------------------------------------------------------------------
 template <typename FT, int UVS, bool WINDOW>
-__global__ __launch_bounds__(kBlock) void advect_step_kernel(StepArgs a)
+__global__ __launch_bounds__(kBlock, 8) void advect_step_kernel(StepArgs a)
 {
     const unsigned blk = (a.tune & TUNE_XCD_REMAP) ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
     int64_t p = (int64_t)blk * kBlock + threadIdx.x;
@@ -244,7 +244,7 @@ struct RunArgs {
 };
 
 template <typename FT, int UVS, bool WINDOW>
-__global__ __launch_bounds__(kBlock) void advect_run_kernel(RunArgs ra)
+__global__ __launch_bounds__(kBlock, 8) void advect_run_kernel(RunArgs ra)
 {
     const StepArgs &a = ra.s;
     const unsigned blk = (a.tune & TUNE_XCD_REMAP) ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;

@@ -59,11 +59,12 @@ def main():
         for c in sorted(counters[k]):
             v = counters[k][c]
             avg.setdefault(k, {})[c] = sum(v) / len(v)
-            if not ("advect_step" in k or "build_geo" in k or "permute_state" in k or "radix_sort" in k):
+            if not ("advect_" in k or "build_geo" in k or "survive_mask" in k):
                 continue                  # keep the table to the kernels that matter; all averages stay in `avg`
             lines.append("| `%s` | %s | %d | %.6g |" % (k, c, len(v), avg[k][c]))
     res = {"tag": tag, "config": config}
-    adv = next((k for k in avg if "advect_step_kernel" in k), None)
+    adv = next((k for k in avg if "advect_run_kernel" in k), None) or next((k for k in avg if "advect_step_kernel" in k), None)
+    fused = adv is not None and "advect_run_kernel" in adv
     lines += ["", "## HBM traffic of the dominant kernel", ""]
     if adv and "FETCH_SIZE" in avg[adv] and "WRITE_SIZE" in avg[adv]:
         a = avg[adv]
@@ -101,7 +102,7 @@ def main():
     tj = os.path.join(root, "profiles", "traffic.json")
     allt = json.load(open(tj)) if os.path.exists(tj) else {}
     if "hbm_bytes_per_launch" in res:
-        allt[config] = {"hbm_bytes_per_launch": res["hbm_bytes_per_launch"], "source": os.path.basename(out_md)}
+        allt[config + "_fused" if fused else config] = {"hbm_bytes_per_launch": res["hbm_bytes_per_launch"], "source": os.path.basename(out_md)}
         json.dump(allt, open(tj, "w"), indent=1)
     print("\n".join(lines))
 
