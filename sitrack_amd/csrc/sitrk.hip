@@ -449,13 +449,18 @@ template <typename FT>
 static void launch_run(sitrk_ctx *h, const RunArgs &ra)
 {
     dim3 grid(nblocks(ra.s.nP)), block(kBlock);
-    if (h->uv_strategy == 1) {
-        if (h->windowed) hipLaunchKernelGGL((advect_run_kernel<FT, 1, true>), grid, block, 0, h->stream, ra);
-        else hipLaunchKernelGGL((advect_run_kernel<FT, 1, false>), grid, block, 0, h->stream, ra);
-    } else {
-        if (h->windowed) hipLaunchKernelGGL((advect_run_kernel<FT, 0, true>), grid, block, 0, h->stream, ra);
-        else hipLaunchKernelGGL((advect_run_kernel<FT, 0, false>), grid, block, 0, h->stream, ra);
-    }
+#define SITRK_LAUNCH_RUN(KERNEL)                                                                          \
+    do {                                                                                                  \
+        if (h->uv_strategy == 1) {                                                                        \
+            if (h->windowed) hipLaunchKernelGGL((KERNEL<FT, 1, true>), grid, block, 0, h->stream, ra);    \
+            else hipLaunchKernelGGL((KERNEL<FT, 1, false>), grid, block, 0, h->stream, ra);               \
+        } else {                                                                                          \
+            if (h->windowed) hipLaunchKernelGGL((KERNEL<FT, 0, true>), grid, block, 0, h->stream, ra);    \
+            else hipLaunchKernelGGL((KERNEL<FT, 0, false>), grid, block, 0, h->stream, ra);               \
+        }                                                                                                 \
+    } while (0)
+    SITRK_LAUNCH_RUN(advect_run_kernel);
+#undef SITRK_LAUNCH_RUN
 }
 
 SITRK_API int sitrk_run(sitrk_t *h, int slot0, int jrec0, int nsteps)

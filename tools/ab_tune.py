@@ -46,7 +46,6 @@ def main():
     allk = knobs + singles
     variants = [dict({k: 0 for k in allk}, **v) for v in variants] + [dict({k: 0 for k in allk}, **{k: 1}) for k in singles]
     base = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in a.base.split(",") if kv)
-    variants = [dict(v, sort_tile=0) for v in variants]
     for t in [t for t in a.tiles.split(",") if t]:
         tj, ti = (int(x) for x in t.split("x"))
         variants.append(dict({k: 0 for k in allk}, sort_tile=tj * 256 + ti))
