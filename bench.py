@@ -148,7 +148,7 @@ def main():
                 ctx.push_record(k, u[k], v[k], sic[k])
 
     ctx.set_buoys(yx, ji, sort=not a.no_sort)
-    resort = a.resort if a.resort >= 0 else 0
+    resort = a.resort if a.resort >= 0 else 512        # measured over 6000 steps: 512 > 256 > 128 > never
     ctx.set_resort(0 if a.no_sort else resort)
 
     def barrier():

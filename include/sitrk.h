@@ -109,7 +109,7 @@ int sitrk_set_buoys(sitrk_t *h, int64_t nP, const double *yx, const int32_t *jiT
 
 /* re-order the device-resident buoys by host cell (coalescing); results are
  * always returned in the caller's original order.  resort_every > 0 re-sorts
- * automatically every that many steps. */
+ * automatically every that many steps (default 512; 0 = never). */
 int sitrk_sort_buoys(sitrk_t *h);
 int sitrk_set_resort(sitrk_t *h, int resort_every);
 

@@ -63,7 +63,7 @@ struct sitrk_ctx {
     int32_t *vals[2] = {nullptr, nullptr};
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
-    int resort_every = 0;
+    int resort_every = 512;             // re-sort cadence in steps (0 = never); measured best over 6000 steps at C3
     int steps_since_sort = 0;
     bool sorted_once = false;
 
