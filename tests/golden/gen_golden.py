@@ -404,10 +404,28 @@ def g9_haversine():
     save("g9_haversine.npz", plat=plat, plon=plon, xlat=xlat, xlon=xlon, dist=d)
 
 
+# --------------------------------------------------------------------------- G10
+def g10_nemoseed():
+    rng = np.random.default_rng(1241)
+    Nj, Ni = 37, 41
+    lat = 50. + 40. * rng.random((Nj, Ni))
+    lon = 360. * rng.random((Nj, Ni))
+    latF = lat + 0.05; lonF = lon + 0.07
+    tmask = (rng.random((Nj, Ni)) > 0.1).astype('i1')
+    sic = rng.choice([0.0, 0.5, 0.89, 0.9, 0.95, 1.0], size=(Nj, Ni))
+    rmask = (rng.random((Nj, Ni)) > 0.3).astype('i1')
+    out = {}
+    for tag, kw in (("a", dict(khss=1)), ("b", dict(khss=3)), ("c", dict(khss=2, fmsk_rstrct=rmask)),
+                    ("d", dict(khss=1, platF=latF, plonF=lonF)), ("e", dict(khss=4, fmsk_rstrct=rmask, platF=latF, plonF=lonF))):
+        with quiet():
+            out["seed_" + tag] = tracking.nemoSeed(tmask, lat, lon, sic, **kw)
+    save("g10_nemoseed.npz", lat=lat, lon=lon, latF=latF, lonF=lonF, tmask=tmask, sic=sic, rmask=rmask, **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, fn in (("g1", g1_inside), ("g2", g2_intersect), ("g3", g3_crossing), ("g4", g4_survive),
                      ("g5", g5_seedinit), ("g6", g6_trajectories), ("g7", g7_projection), ("g8", g8_timespan),
-                     ("g9", g9_haversine)):
+                     ("g9", g9_haversine), ("g10", g10_nemoseed)):
         if not only or name in only:
             fn()

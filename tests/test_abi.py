@@ -68,3 +68,15 @@ def test_get_time_span_matches_golden(golden):
 def test_vertices_are_a_function_of_the_cell(golden):
     g = golden("g5_seedinit.npz")
     assert np.array_equal(sit.vertices_of(g["ojiT"]), g["overt"])
+
+
+def test_nemoseed_matches_reference_golden(golden):
+    from sitrack_amd.seeding import nemoSeed
+    g = golden("g10_nemoseed.npz")
+    cases = {"a": dict(khss=1), "b": dict(khss=3), "c": dict(khss=2, fmsk_rstrct=g["rmask"]),
+             "d": dict(khss=1, platF=g["latF"], plonF=g["lonF"]),
+             "e": dict(khss=4, fmsk_rstrct=g["rmask"], platF=g["latF"], plonF=g["lonF"])}
+    for tag, kw in cases.items():
+        got = nemoSeed(g["tmask"], g["lat"], g["lon"], g["sic"], **kw)
+        assert np.array_equal(got, g["seed_" + tag]), tag
+        assert len(got) > 0

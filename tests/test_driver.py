@@ -200,3 +200,23 @@ def test_cli_end_to_end_vs_oracle(tmp_path, monkeypatch, two_d_time):
     # second run hits the seed cache and reproduces the same result
     out2 = drv.main(argv)
     assert np.array_equal(out2["vJIt"], out["vJIt"]) and np.array_equal(out2["iAlive"], out["iAlive"])
+
+
+@pytest.mark.gpu
+def test_seeding_tool_feeds_the_tracker(tmp_path, monkeypatch):
+    """tools/generate_idealized_seeding.py -> si3_part_tracker.py, reference README.md:36-97 workflow."""
+    import importlib.util
+    monkeypatch.chdir(tmp_path)
+    c = make_case(str(tmp_path))
+    spec = importlib.util.spec_from_file_location("gis", os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools",
+                                                                      "generate_idealized_seeding.py"))
+    gis = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gis)
+    f = gis.main(["-d", "1996-12-15_00:00:00", "-m", c["mm"], "-i", c["si3"], "-k", "0", "-S", "3", "-N", "TEST4"])
+    assert f == './nc/sitrack_seeding_nemoTsi3_19961215_00_HSS3.nc'
+    t, ids, ll, yx = ncio.LoadNCdata(f, krec=0)
+    assert len(ids) > 50 and np.array_equal(ids, np.arange(1, len(ids) + 1)) and int(t) == c["base"]
+    assert np.all(ll[:, 0] >= 55.)
+    out = drv.main(["-i", c["si3"], "-m", c["mm"], "-s", f, "-N", "TEST4", "-F", "-e", "1996-12-15_10:00:00"])
+    assert out["Nt"] == 10 and out["nP"] <= len(ids)
+    assert out["files"][0] == './nc/NEMO-SI3_TEST4_EXP01_tracking_nemoTsi3_idlSeed_19961215h00_19961215h10.nc'

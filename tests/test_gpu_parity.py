@@ -170,6 +170,72 @@ def test_rim_cells_and_negative_index_wrap():
     trk.close()
 
 
+def test_fill_values_nan_and_empty_windows():
+    """Land points of NEMO output carry raw fill data (reference si3_part_tracker.py:372-374 assigns masked slabs
+    into plain arrays): huge values, NaN.  Buoys that pick them up must behave exactly like in the reference
+    arithmetic (NaN positions propagate, every comparison with NaN is false).  Windows may be empty."""
+    Nj, Ni = 64, 72
+    grid = syn.make_grid(Nj, Ni, dkm=4.0, warp=1.0)
+    u, v, sic = syn.make_fields(grid, K=2, seed=6, umax=0.8, drift=0.3)
+    tmask = grid["tmask"].copy()
+    u[:, 20:26, 20:30] = np.nan; v[:, 30:36, 40:50] = 1.0e20; u[:, 40:44, 10:20] = -1.0e20; v[:, 10:14, 50:60] = np.inf
+    _, yx = syn.make_buoys(grid, 6000, seed=8, frac=0.8)
+    trk = make_tracker(grid, tmask, 2)
+    found, ji, _ = sit.FindContainingCell(yx, syn.nearest_t_plane(grid, yx), ctx=trk.ctx)
+    yx, ji = yx[found], ji[found]
+    n = len(yx)
+    first = np.zeros(n, dtype=np.int64); last = np.full(n, 100, dtype=np.int64)
+    first[::9] = 5; last[::9] = 3              # empty window: never steps
+    first[1::9] = 4; last[1::9] = 4            # one single record
+    trk.set_buoys(yx, ji, first, last)
+    trk.ctx.set_tuning(fuse=1)
+    g2 = dict(grid); g2["tmask"] = tmask
+    ref = orc.Tracker(g2, yx, ji, rec_first=first, rec_last=last)
+    for k in range(2):
+        trk.load_record(k, u[k], v[k], sic[k])
+    for jrec in range(10):
+        trk.step(jrec, jrec % 2)
+        pn, mn = trk.record(jrec)
+        rp, rm = ref.step(jrec, u[jrec % 2], v[jrec % 2], sic[jrec % 2])
+        assert np.array_equal(mn, rm), jrec
+        assert np.array_equal(pn, rp, equal_nan=True), jrec
+    st = trk.state()
+    assert np.array_equal(st["vJIt"], ref.jiT) and np.array_equal(st["iAlive"], ref.alive)
+    assert np.array_equal(st["yx"], ref.pos, equal_nan=True)
+    assert np.isnan(ref.pos).any() and np.array_equal(st["yx"][::9], yx[::9])
+    # the fused path agrees too
+    trk2 = make_tracker(grid, tmask, 2)
+    trk2.set_buoys(yx, ji, first, last)
+    for k in range(2):
+        trk2.load_record(k, u[k], v[k], sic[k])
+    trk2.ctx.run(0, 0, 10)
+    st2 = trk2.state()
+    assert np.array_equal(st2["yx"], st["yx"], equal_nan=True) and np.array_equal(st2["vJIt"], st["vJIt"])
+    assert np.array_equal(st2["kill_rec"], st["kill_rec"])
+    trk.close(); trk2.close()
+
+
+def test_everything_dies_and_stays_dead():
+    grid = syn.make_grid(32, 32, dkm=4.0)
+    u, v, sic = syn.make_fields(grid, K=1, umax=0.3)
+    sic[:] = 0.0                                  # open water everywhere: any crossing kills
+    _, yx = syn.make_buoys(grid, 500, seed=2, frac=0.5)
+    trk = make_tracker(grid, grid["tmask"], 1)
+    found, ji, _ = sit.FindContainingCell(yx, syn.nearest_t_guess(grid, yx), ctx=trk.ctx)
+    trk.set_buoys(yx[found], ji[found])
+    trk.load_record(0, 10 * u[0], 10 * v[0], sic[0])
+    ref = orc.Tracker(grid, yx[found], ji[found])
+    trk.ctx.run(0, 0, 40)
+    for jrec in range(40):
+        ref.step(jrec, 10 * u[0], 10 * v[0], sic[0], want_out=False)
+    st = trk.state()
+    assert np.array_equal(st["iAlive"], ref.alive) and np.array_equal(st["yx"], ref.pos) and np.array_equal(st["vJIt"], ref.jiT)
+    assert trk.alive_count() == int(ref.alive.sum()) and ref.alive.sum() < 0.5 * len(ref.alive)
+    pos, msk = trk.record(39)
+    assert np.all(pos[st["iAlive"] == 0][st["kill_rec"][st["iAlive"] == 0] < 39] == -9999.)
+    trk.close()
+
+
 def test_run_many_steps_equals_stepping(ctx):
     grid = syn.make_grid(96, 96, dkm=4.0, warp=1.0)
     u, v, sic = syn.make_fields(grid, K=3, seed=3, umax=0.6, drift=0.2)
