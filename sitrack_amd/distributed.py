@@ -96,3 +96,81 @@ def gather_ranges(local, nP, group=None, dst=0):
 def split_slab(slab, Nj, Ni):
     n = Nj * Ni
     return slab[:n].reshape(Nj, Ni), slab[n:2 * n].reshape(Nj, Ni), slab[2 * n:3 * n].reshape(Nj, Ni)
+
+
+class Comm:
+    """What the driver needs from `torch.distributed`, with a trivial single-process form.
+
+    One process per GPU (`torchrun --nproc-per-node N si3_part_tracker.py ...`).  Backend "nccl" (RCCL over xGMI)
+    broadcasts each record slab in place into the resident slot; backend "gloo" (env SITRK_DIST_BACKEND=gloo) moves
+    host arrays instead and exists to rehearse the N>1 logic where RCCL cannot run (several ranks on one GPU, CPU)."""
+
+    def __init__(self):
+        import os
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.backend = None
+        self.dist = None
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            self.backend = os.environ.get("SITRK_DIST_BACKEND", "nccl")
+            self.device = int(os.environ.get("SITRK_DEVICE", str(self.local_rank)))
+            if self.backend == "nccl":
+                torch.cuda.set_device(self.device)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.device))
+            else:
+                dist.init_process_group(self.backend)
+            self.dist = dist
+        else:
+            self.device = None
+
+    @property
+    def root(self):
+        return self.rank == 0
+
+    def range(self, n):
+        return buoy_range(n, self.rank, self.world)
+
+    def bcast_obj(self, obj, src=0):
+        if self.world == 1:
+            return obj
+        box = [obj if self.rank == src else None]
+        self.dist.broadcast_object_list(box, src=src)
+        return box[0]
+
+    def allgather_obj(self, obj):
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def sum_int(self, n):
+        if self.world == 1:
+            return int(n)
+        return int(sum(self.allgather_obj(int(n))))
+
+    def gather_rows(self, local, n_total):
+        """rank 0: rows of every rank concatenated in rank (= buoy) order; others: None."""
+        if self.world == 1:
+            return local
+        return gather_ranges(local, n_total)
+
+    def deliver_record(self, ctx, slot, fields):
+        """`fields` = (u, v, sic) arrays on rank 0, None elsewhere: make the record resident in `slot` everywhere."""
+        if self.world == 1:
+            ctx.push_record(slot, *fields)
+        elif self.backend == "nccl":
+            slab = pack_slab(*fields, dtype=ctx.field_dtype) if self.root else None
+            broadcast_record(ctx, slot, slab, src=0)
+        else:
+            slab = pack_slab(*fields, dtype=ctx.field_dtype) if self.root else None
+            slab = broadcast_record_host(slab, ctx.slab_elems, ctx.field_dtype, src=0)
+            ctx.push_record(slot, *split_slab(slab, ctx.Nj, ctx.Ni))
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()

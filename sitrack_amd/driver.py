@@ -5,7 +5,9 @@ Same flags and defaults (reference si3_part_tracker.py:42-73), same module const
 `./seed/Initialized_buoys_<SeedName>_<CONF>.npz` cache keys (:205-255), same per-buoy record windows in
 2-D-time mode (:264-318), same NetCDF outputs (:515-571) -- the per-buoy loop (:378-490) and the
 per-record inverse projection (:493) run on the GPU.  Differences, all opt-in or forced:
-extra flags `--device`, `--uv-strategy`; errors raise instead of `print; exit(0)`; maps need the
+extra flags `--device`, `--uv-strategy`; under `torchrun` (WORLD_SIZE > 1) the buoys are range-partitioned over the
+ranks, rank 0 reads each record and broadcasts its slab (RCCL), rank 0 writes the files; errors raise instead of
+`print; exit(0)`; maps need the
 optional `mojito` package and are skipped without it; the full (Nt+1,nP,2) series is only kept in
 host memory when it is written (`-F`) instead of always (the reference's 320 GB at 1e7 buoys x 1000 records).
 """
@@ -17,6 +19,7 @@ from os import path
 import numpy as np
 
 from . import _lib, ncio
+from .distributed import Comm
 from .tracking import GetTimeSpan, IceTracker, SeedInit
 
 rdt = 3600.          # time step [s] = model output period (reference :31)
@@ -105,8 +108,11 @@ def main(argv=None):
     cf_uv, cf_mm, fNCseed, jrecSeed, cdate_stop, CONF = a.fsi3, a.fmmm, a.fsdg, a.krec, a.dend, a.ncnf
     lUse2DTime = not a.fxdt
     iUVstrategy = a.uv_strategy
-    print('\n *** SITRACK ice particule tracker, GPU build; NetCDF backend = ' + ncio.backend())
-    print(' *** SI3 file =>', cf_uv, '\n *** mesh_mask =>', cf_mm, '\n *** seeding  =>', fNCseed, jrecSeed)
+    comm = Comm()
+    say = print if comm.root else (lambda *args, **kw: None)
+    say('\n *** SITRACK ice particule tracker, GPU build; NetCDF backend = ' + ncio.backend()
+        + ('; %d ranks (%s)' % (comm.world, comm.backend) if comm.world > 1 else ''))
+    say(' *** SI3 file =>', cf_uv, '\n *** mesh_mask =>', cf_mm, '\n *** seeding  =>', fNCseed, jrecSeed)
 
     cdtbin, csfkm = seed_name_tokens(path.basename(fNCseed))
     idateSeedA, idateSeedB, SeedName, SeedBatch, zTpos = ncio.SeedFileTimeInfo(fNCseed, ltime2d=lUse2DTime)
@@ -119,13 +125,15 @@ def main(argv=None):
         date_stop = idateSeedB                      # several records in the seeding file: replicate its time span (:168-172)
     Nt, kstrt, kstop, iTmA, iTmB = GetTimeSpan(rdt, ztime_model, idateSeedA, idateModA, idateModB, iStop=date_stop)
     if Nt < 1:
-        print(' QUITTING since no matching model records!')
+        say(' QUITTING since no matching model records!')
+        comm.close()
         return 0
-    print(' *** model records %d..%d (%d records): %s -> %s' % (kstrt, kstop, Nt, epoch2clock(iTmA), epoch2clock(iTmB)))
-    for cd in ('seed', 'nc', 'npz'):
-        os.makedirs(cd, exist_ok=True)
+    say(' *** model records %d..%d (%d records): %s -> %s' % (kstrt, kstop, Nt, epoch2clock(iTmA), epoch2clock(iTmB)))
+    if comm.root:
+        for cd in ('seed', 'nc', 'npz'):
+            os.makedirs(cd, exist_ok=True)
 
-    ctx = _lib.Context(a.device)
+    ctx = _lib.Context(a.device if comm.world == 1 else comm.device)
     imaskt, xlatT, xlonT, xYt, xXt, xYf, xXf, xResKM = ncio.GetModelGrid(cf_mm, ctx)
     if iUVstrategy == 1:
         xYv, xXv, xYu, xXu = ncio.GetModelUVGrid(cf_mm, ctx)
@@ -134,23 +142,32 @@ def main(argv=None):
     (Nj, Ni) = np.shape(imaskt)
     records = ncio.ModelRecords(cf_uv)
 
-    # ---- seeding, with the reference's intermediate cache (:205-255)
+    # ---- seeding, with the reference's intermediate cache (:205-255).  Seeds are independent: with several ranks
+    #      each one locates its own contiguous range and the results are concatenated in rank (= seed) order.
     cf_npz_itm = './seed/Initialized_buoys_' + SeedName + '_' + CONF + '.npz'
-    if path.exists(cf_npz_itm):
-        print(' *** using cached seed initialisation ' + cf_npz_itm)
-        with np.load(cf_npz_itm) as data:
-            nP = int(data['nP']); xPosG0 = data['xPosG0']; xPosC0 = data['xPosC0']; IDs = data['IDs']
-            vJIt = data['vJIt']; VRTCS = data['VRTCS']; idxK = data['idxKeep']
+    if comm.bcast_obj(path.exists(cf_npz_itm)):
+        say(' *** using cached seed initialisation ' + cf_npz_itm)
+        pack = None
+        if comm.root:
+            with np.load(cf_npz_itm) as data:
+                pack = (int(data['nP']), data['xPosG0'], data['xPosC0'], data['IDs'], data['vJIt'], data['VRTCS'], data['idxKeep'])
+        nP, xPosG0, xPosC0, IDs, vJIt, VRTCS, idxK = comm.bcast_obj(pack)
     else:
         (xIC,) = records.fields(kstrt, ('siconc',))
         zt, zIDs, XseedG, XseedC = ncio.LoadNCdata(fNCseed, krec=jrecSeed)
         (nP0, _) = np.shape(XseedG)
         IDs = np.array(zIDs, dtype=int)
-        nP, xPosG0, xPosC0, IDs, vJIt, VRTCS, idxK = SeedInit(IDs, XseedG, XseedC, xlatT, xlonT, xYf, xXf, xResKM, imaskt,
-                                                              xIceConc=np.asarray(xIC, dtype=np.float64), ctx=ctx)
+        lo, hi = comm.range(nP0)
+        part = SeedInit(IDs[lo:hi], XseedG[lo:hi], XseedC[lo:hi], xlatT, xlonT, xYf, xXf, xResKM, imaskt,
+                        xIceConc=np.asarray(xIC, dtype=np.float64), ctx=ctx)
+        parts = comm.allgather_obj((lo,) + part)
+        nP = sum(q[1] for q in parts)
+        xPosG0, xPosC0, IDs, vJIt, VRTCS = (np.concatenate([q[k] for q in parts], axis=0) for k in (2, 3, 4, 5, 6))
+        idxK = np.concatenate([q[0] + q[7] for q in parts])
         if nP < nP0:
-            print(' *** `SeedInit()` had to cancel ' + str(nP0 - nP) + ' buoys! => nP = ' + str(nP))
-        np.savez_compressed(cf_npz_itm, nP=nP, xPosG0=xPosG0, xPosC0=xPosC0, IDs=IDs, vJIt=vJIt, VRTCS=VRTCS, idxKeep=idxK)
+            say(' *** `SeedInit()` had to cancel ' + str(nP0 - nP) + ' buoys! => nP = ' + str(nP))
+        if comm.root:
+            np.savez_compressed(cf_npz_itm, nP=nP, xPosG0=xPosG0, xPosC0=xPosC0, IDs=IDs, vJIt=vJIt, VRTCS=VRTCS, idxKeep=idxK)
 
     # ---- per-buoy record windows (:264-318)
     z1stModelRec = np.zeros(nP, dtype=int) + kstrt
@@ -160,23 +177,24 @@ def main(argv=None):
         if zTpos.shape != (2, nP) and zTpos.ndim == 2 and zTpos.shape[1] > nP and len(idxK) == nP:
             # SeedInit cancelled buoys: keep the time positions of the survivors.  (The reference has this line
             # commented out, si3_part_tracker.py:250, and then stops on the shape check of :269-272.)
-            print(' *** adjusting `zTpos` to the %d buoys kept by SeedInit' % nP)
+            say(' *** adjusting `zTpos` to the %d buoys kept by SeedInit' % nP)
             zTpos = zTpos[:, idxK]
         if zTpos.shape != (2, nP):
             raise ValueError('wrong shape for the 2D time array `zTpos`: %s vs nP=%d' % (zTpos.shape, nP))
         z1stModelRec, zLstModelRec = record_windows(zTpos, ztime_model, kstrt, kstop, iTmA, iTmB, nP)
     k0 = z1stModelRec - kstrt
 
-    # ---- device state
+    # ---- device state: this rank's contiguous range [lo,hi) of the buoys
+    lo, hi = comm.range(nP)
     (u0,) = records.fields(kstrt, ('u_ice',))
     fdt = np.float64 if np.asarray(u0).dtype == np.float64 else np.float32
     trk = IceTracker(xYf, xXf, xYu, xXu, xYv, xXv, imaskt, rdt=rdt, iUVstrategy=iUVstrategy, nslots=1, field_dtype=fdt, ctx=ctx)
-    trk.set_buoys(xPosC0, vJIt, z1stModelRec if lUse2DTime else None, zLstModelRec if lUse2DTime else None)
+    trk.set_buoys(xPosC0[lo:hi], vJIt[lo:hi], z1stModelRec[lo:hi] if lUse2DTime else None, zLstModelRec[lo:hi] if lUse2DTime else None)
 
-    # ---- host arrays: the full series only when it is written
+    # ---- host arrays (rank 0): the full series only when it is written
     lFull = (not lUse2DTime) or a.plot > 0
     vTime = np.zeros(Nt + 1, dtype=int)
-    if lFull:
+    if lFull and comm.root:
         xmask = np.zeros((Nt + 1, nP), dtype='i1')
         xPosC = np.zeros((Nt + 1, nP, 2)) + FILL
         xPosG = np.zeros((Nt + 1, nP, 2)) + FILL
@@ -184,16 +202,17 @@ def main(argv=None):
         xPosG[k0, np.arange(nP), :] = xPosG0
         xmask[k0, np.arange(nP)] = 1
     if lUse2DTime:
-        z2XY, z2GC = np.zeros((2, nP, 2)) + FILL, np.zeros((2, nP, 2)) + FILL
-        zMSK, zTim = np.zeros((2, nP), dtype='i1'), np.zeros((2, nP), dtype=int) + int(FILL)
-        z2XY[0], z2GC[0], zMSK[0] = xPosC0, xPosG0, 1
-        zTim[0] = ztime_model[z1stModelRec] - int(rdt / 2)
-        # a buoy whose window opens later has its seed position pre-written at record k0, and the reference converts
-        # that row to lat/lon when it passes over record k0-1 (:493)
-        late = k0 > 0
-        if np.any(late):
-            z2GC[0, late] = ctx.cart2geo(xPosC0[late])
         ends = set(np.unique(zLstModelRec).tolist())
+        if comm.root:
+            z2XY, z2GC = np.zeros((2, nP, 2)) + FILL, np.zeros((2, nP, 2)) + FILL
+            zMSK, zTim = np.zeros((2, nP), dtype='i1'), np.zeros((2, nP), dtype=int) + int(FILL)
+            z2XY[0], z2GC[0], zMSK[0] = xPosC0, xPosG0, 1
+            zTim[0] = ztime_model[z1stModelRec] - int(rdt / 2)
+            # a buoy whose window opens later has its seed position pre-written at record k0, and the reference converts
+            # that row to lat/lon when it passes over record k0-1 (:493)
+            late = k0 > 0
+            if np.any(late):
+                z2GC[0, late] = ctx.cart2geo(xPosC0[late])
 
     # ---- the record loop (:361-496)
     for jt in range(Nt):
@@ -201,26 +220,38 @@ def main(argv=None):
         itmod = records.time(jrec)
         itime = itmod - int(rdt / 2.)
         vTime[jt] = itime
-        xUu, xVv, xIC = records.fields(jrec)
-        print(' *** record #%d/%d  date = %s   buoys alive = %d' % (jrec + 1, Nt0, epoch2clock(itime), trk.alive_count()))
-        trk.load_record(0, xUu, xVv, xIC)
+        nalive = comm.sum_int(trk.alive_count())
+        say(' *** record #%d/%d  date = %s   buoys alive = %d' % (jrec + 1, Nt0, epoch2clock(itime), nalive))
+        fields = records.fields(jrec) if comm.root else None          # rank 0 ingests the record (:372-374) ...
+        if comm.world == 1:
+            trk.load_record(0, *fields)
+        else:
+            comm.deliver_record(ctx, 0, fields)                         # ... and broadcasts its slab
         trk.step(jrec, 0)
         need = lFull or (lUse2DTime and jrec in ends)
         if need:
-            pos, msk = trk.record(jrec)
+            pos_l, msk_l = trk.record(jrec)
+            pos, msk = comm.gather_rows(pos_l, nP), comm.gather_rows(msk_l, nP)
+        if need and comm.root:
             stepped = msk == 1
-        if lFull:
-            xPosC[jt + 1, stepped] = pos[stepped]
-            xmask[jt + 1, stepped] = 1
-            xPosG[jt + 1] = ctx.cart2geo(xPosC[jt + 1])
-        if lUse2DTime and jrec in ends:
-            sel = np.where(zLstModelRec == jrec)[0]
-            z2XY[1, sel] = pos[sel]
-            z2GC[1, sel] = ctx.cart2geo(pos[sel])
-            zMSK[1, sel] = msk[sel]
-            zTim[1, sel[stepped[sel]]] = int(itime + rdt)
+            if lFull:
+                xPosC[jt + 1, stepped] = pos[stepped]
+                xmask[jt + 1, stepped] = 1
+                xPosG[jt + 1] = ctx.cart2geo(xPosC[jt + 1])
+            if lUse2DTime and jrec in ends:
+                sel = np.where(zLstModelRec == jrec)[0]
+                z2XY[1, sel] = pos[sel]
+                z2GC[1, sel] = ctx.cart2geo(pos[sel])
+                zMSK[1, sel] = msk[sel]
+                zTim[1, sel[stepped[sel]]] = int(itime + rdt)
     records.close()
     vTime[Nt] = vTime[Nt - 1] + int(rdt)
+    state = trk.state()
+    vJIt_end, alive_end = comm.gather_rows(state["vJIt"], nP), comm.gather_rows(state["iAlive"], nP)
+    trk.close()
+    if not comm.root:
+        comm.close()
+        return {"rank": comm.rank, "nP": nP, "range": (lo, hi)}
 
     # ---- outputs (:509-571)
     corgn = 'NEMO-SI3_' + ModConf + '_' + ModExp
@@ -249,6 +280,5 @@ def main(argv=None):
     print(' *** first and final dates in simulated trajectories:', epoch2clock(zvt[0]), epoch2clock(zvt[1]))
     for f in outs:
         print('      ===> ' + f + ' saved!')
-    state = trk.state()
-    trk.close()
-    return {"files": outs, "nP": nP, "IDs": IDs, "vJIt": state["vJIt"], "iAlive": state["iAlive"], "Nt": Nt, "kstrt": kstrt}
+    comm.close()
+    return {"files": outs, "nP": nP, "IDs": IDs, "vJIt": vJIt_end, "iAlive": alive_end, "Nt": Nt, "kstrt": kstrt}

@@ -220,3 +220,45 @@ def test_seeding_tool_feeds_the_tracker(tmp_path, monkeypatch):
     out = drv.main(["-i", c["si3"], "-m", c["mm"], "-s", f, "-N", "TEST4", "-F", "-e", "1996-12-15_10:00:00"])
     assert out["Nt"] == 10 and out["nP"] <= len(ids)
     assert out["files"][0] == './nc/NEMO-SI3_TEST4_EXP01_tracking_nemoTsi3_idlSeed_19961215h00_19961215h10.nc'
+
+
+def _dist_worker(rank, world, port, tmp, argv, q):
+    os.environ.update({"WORLD_SIZE": str(world), "RANK": str(rank), "LOCAL_RANK": str(rank), "MASTER_ADDR": "127.0.0.1",
+                       "MASTER_PORT": str(port), "SITRK_DIST_BACKEND": "gloo", "SITRK_DEVICE": "0"})
+    os.chdir(tmp)
+    out = drv.main(argv)
+    if rank == 0:
+        q.put({k: out[k] for k in ("files", "nP", "IDs", "vJIt", "iAlive")})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("two_d_time", [False, True])
+def test_cli_two_ranks_equals_one(tmp_path, monkeypatch, two_d_time):
+    """N>1 driver path rehearsed with 2 ranks on the one GPU of the box (gloo moves the record slabs; RCCL refuses
+    two ranks per device): buoy-range partition, per-range SeedInit, record delivery, gathers -> same files."""
+    import socket
+    import torch.multiprocessing as mp
+    d1, d2 = tmp_path / "one", tmp_path / "two"
+    d1.mkdir(); d2.mkdir()
+    c = make_case(str(tmp_path), two_d_time=two_d_time)
+    argv = ["-i", c["si3"], "-m", c["mm"], "-s", c["seed"], "-N", "TEST4"] + ([] if two_d_time else ["-F"])
+    monkeypatch.chdir(d1)
+    one = drv.main(argv)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dist_worker, args=(r, 2, port, str(d2), argv, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    two = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert two["nP"] == one["nP"] and np.array_equal(two["IDs"], one["IDs"])
+    assert np.array_equal(two["vJIt"], one["vJIt"]) and np.array_equal(two["iAlive"], one["iAlive"])
+    assert two["files"] == one["files"]
+    for f in one["files"]:
+        a = ncio.LoadNCdata(str(d1 / f), krec=-1, lmask=True)
+        b = ncio.LoadNCdata(str(d2 / f), krec=-1, lmask=True)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
