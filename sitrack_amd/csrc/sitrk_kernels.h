@@ -164,29 +164,19 @@ struct StepArgs {
 };
 
 // ---------------------------------------------------------------------------
-// One model record for every buoy -- body of si3_part_tracker.py:378-490.
-//   UVS    : iUVstrategy (:37-40)   1 nearest U/V point, 0 cell mean
-//   WINDOW : per-buoy first/last model record (2-D time mode, :264-318,380)
+// Everything ONE buoy does for ONE model record: the body of the reference's per-buoy loop
+// (si3_part_tracker.py:382-484).  P = (ry,rx) and the packed host cell c are updated in place;
+// returns false when Survive killed the buoy (its position is still advanced: the reference writes
+// xPosC[jt+1] before the kill test, :459-460 vs :483-484).
+//   UVS : iUVstrategy (:37-40)   1 nearest U/V point, 0 cell mean
 // ---------------------------------------------------------------------------
-template <typename FT, int UVS, bool WINDOW>
-__global__ __launch_bounds__(kBlock, 8) void advect_step_kernel(StepArgs a)
+template <typename FT, int UVS>
+__device__ __forceinline__ bool advance_record(const StepArgs &a, const FT *__restrict__ u, const FT *__restrict__ v,
+                                               const int8_t *__restrict__ kill, pt &P, int32_t &c)
 {
-    const unsigned blk = (a.tune & TUNE_XCD_REMAP) ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
-    int64_t p = (int64_t)blk * kBlock + threadIdx.x;
-    if (p >= a.nP) return;
-    const bool nt = (a.tune & TUNE_NT_STATE) != 0;
-    int32_t c = nt ? __builtin_nontemporal_load(&a.cell[p]) : a.cell[p];
-    if (c < 0) return;                                   // iAlive != 1
-    if (WINDOW) {
-        if (a.jrec < a.first[p] || a.jrec > a.last[p]) return;
-    }
     const int Ni = a.Ni, Nj = a.Nj;
     const int jT = cell_j(c), iT = cell_i(c);
     const size_t k = (size_t)jT * Ni + iT;
-    const FT *__restrict__ u = (const FT *)a.u;
-    const FT *__restrict__ v = (const FT *)a.v;
-
-    const pt P = nt ? load_pt_nt(&a.pos[p]) : a.pos[p];  // (ry, rx)
     // cell (jT,iT): F = upper-right vertex, U = right U-point, V = upper V-point
     const CellGeo g11 = a.geo[k];
     const pt F10 = a.geo[k - 1].f;                       // F[jT  ,iT-1]  upper-left
@@ -200,6 +190,7 @@ __global__ __launch_bounds__(kBlock, 8) void advect_step_kernel(StepArgs a)
     } else {                                             // :427-441
         const pt U10 = a.geo[k - 1].u;                   // U[jT,iT-1]
         const pt V01 = a.geo[k - Ni].v;                  // V[jT-1,iT]
+        // all four candidates are loaded up front: no load depends on a predicate
         const double u1 = (double)u[k], u0 = (double)u[k - 1];
         const double v1 = (double)v[k], v0 = (double)v[k - Ni];
         const bool llum1 = intersect2seg(P, g11.f, V01, g11.v);
@@ -208,22 +199,44 @@ __global__ __launch_bounds__(kBlock, 8) void advect_step_kernel(StepArgs a)
         zV = llvm1 ? v0 : v1;
     }
 
-    // forward Euler, one step per record (:452-458): km += (m/s * s) / 1000
+    // forward Euler, one step per record (:452-458): km += (m/s * s) / 1000   (true divisions, like the reference)
     const double dx = zU * a.rdt;
     const double dy = zV * a.rdt;
     pt Pn;
     Pn.x = P.x + dx / 1000.;
     Pn.y = P.y + dy / 1000.;
-    if (nt) store_pt_nt(&a.pos[p], Pn);                  // written before the kill test (:459-460)
-    else a.pos[p] = Pn;
 
+    bool killed = false;
     // still inside the host cell? (:466) quad = [bl, br, ur, ul]
-    if (!inside_quad(Pn.y, Pn.x, F00, F01, g11.f, F10)) {
-        bool killed;
-        const int32_t cn = resolve_crossing(P, Pn, F00, F01, g11.f, F10, jT, iT, Nj, Ni, a.geo, a.kill, killed);
-        if (killed) a.kill_rec[p] = a.jrec;
-        a.cell[p] = cn;
+    if (!inside_quad(Pn.y, Pn.x, F00, F01, g11.f, F10))
+        c = resolve_crossing(P, Pn, F00, F01, g11.f, F10, jT, iT, Nj, Ni, a.geo, kill, killed);   // :474-484
+    P = Pn;
+    return !killed;
+}
+
+// ---------------------------------------------------------------------------
+// One model record for every buoy, one buoy per lane (sitrk_step).
+//   WINDOW : per-buoy first/last model record (2-D time mode, :264-318,380)
+// ---------------------------------------------------------------------------
+template <typename FT, int UVS, bool WINDOW>
+__global__ __launch_bounds__(kBlock, 8) void advect_step_kernel(StepArgs a)
+{
+    const unsigned blk = (a.tune & TUNE_XCD_REMAP) ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int64_t p = (int64_t)blk * kBlock + threadIdx.x;
+    if (p >= a.nP) return;
+    const bool nt = (a.tune & TUNE_NT_STATE) != 0;
+    int32_t c = nt ? __builtin_nontemporal_load(&a.cell[p]) : a.cell[p];
+    if (c < 0) return;                                   // iAlive != 1 (:380)
+    if (WINDOW) {
+        if (a.jrec < a.first[p] || a.jrec > a.last[p]) return;
     }
+    pt P = nt ? load_pt_nt(&a.pos[p]) : a.pos[p];        // (ry, rx)
+    const int32_t c0 = c;
+    const bool alive = advance_record<FT, UVS>(a, (const FT *)a.u, (const FT *)a.v, a.kill, P, c);
+    if (nt) store_pt_nt(&a.pos[p], P);
+    else a.pos[p] = P;
+    if (!alive) a.kill_rec[p] = a.jrec;
+    if (c != c0) a.cell[p] = c;
 }
 
 // ---------------------------------------------------------------------------
@@ -248,14 +261,13 @@ __global__ __launch_bounds__(kBlock, 8) void advect_run_kernel(RunArgs ra)
 {
     const StepArgs &a = ra.s;
     const unsigned blk = (a.tune & TUNE_XCD_REMAP) ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
-    int64_t p = (int64_t)blk * kBlock + threadIdx.x;
+    const int64_t p = (int64_t)blk * kBlock + threadIdx.x;
     if (p >= a.nP) return;
     const bool nt = (a.tune & TUNE_NT_STATE) != 0;
     int32_t c = nt ? __builtin_nontemporal_load(&a.cell[p]) : a.cell[p];
     if (c < 0) return;
     int first = 0, last = 0x7fffffff;
     if (WINDOW) { first = a.first[p]; last = a.last[p]; }
-    const int Ni = a.Ni, Nj = a.Nj;
     pt P = nt ? load_pt_nt(&a.pos[p]) : a.pos[p];
     const int32_t c0 = c;
     bool moved = false;
@@ -266,44 +278,11 @@ __global__ __launch_bounds__(kBlock, 8) void advect_run_kernel(RunArgs ra)
             if (jrec < first) continue;
             if (jrec > last) break;
         }
-        const int jT = cell_j(c), iT = cell_i(c);
-        const size_t k = (size_t)jT * Ni + iT;
-        const FT *__restrict__ u = (const FT *)ra.u[r];
-        const FT *__restrict__ v = (const FT *)ra.v[r];
-        const CellGeo g11 = a.geo[k];
-        const pt F10 = a.geo[k - 1].f;
-        const pt F01 = a.geo[k - Ni].f;
-        const pt F00 = a.geo[k - Ni - 1].f;
-        double zU, zV;
-        if (UVS == 0) {
-            zU = 0.5 * ((double)u[k] + (double)u[k - 1]);
-            zV = 0.5 * ((double)v[k] + (double)v[k - Ni]);
-        } else {
-            const pt U10 = a.geo[k - 1].u;
-            const pt V01 = a.geo[k - Ni].v;
-            const double u1 = (double)u[k], u0 = (double)u[k - 1];
-            const double v1 = (double)v[k], v0 = (double)v[k - Ni];
-            const bool llum1 = intersect2seg(P, g11.f, V01, g11.v);
-            const bool llvm1 = intersect2seg(P, g11.f, U10, g11.u);
-            zU = llum1 ? u0 : u1;
-            zV = llvm1 ? v0 : v1;
-        }
-        const double dx = zU * a.rdt;
-        const double dy = zV * a.rdt;
-        pt Pn;
-        Pn.x = P.x + dx / 1000.;
-        Pn.y = P.y + dy / 1000.;
         moved = true;
-        if (!inside_quad(Pn.y, Pn.x, F00, F01, g11.f, F10)) {
-            bool killed;
-            c = resolve_crossing(P, Pn, F00, F01, g11.f, F10, jT, iT, Nj, Ni, a.geo, ra.kill[r], killed);
-            if (killed) {
-                a.kill_rec[p] = jrec;
-                P = Pn;
-                break;                                   // dead buoys never step again
-            }
+        if (!advance_record<FT, UVS>(a, (const FT *)ra.u[r], (const FT *)ra.v[r], ra.kill[r], P, c)) {
+            a.kill_rec[p] = jrec;
+            break;                                       // dead buoys never step again
         }
-        P = Pn;
     }
     if (moved) {
         if (nt) store_pt_nt(&a.pos[p], P);
