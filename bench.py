@@ -107,13 +107,21 @@ def main():
     import sitrack_amd as sit
     from sitrack_amd import synthetic as syn
 
+    # backend "nccl" = RCCL over xGMI.  SITRK_DIST_BACKEND=gloo (+ SITRK_DEVICE) rehearses the N>1 code path with several
+    # ranks on ONE GPU (RCCL refuses two ranks per device): the slabs then travel through host memory.
     dist = None
+    backend = os.environ.get("SITRK_DIST_BACKEND", "nccl")
+    dev = int(os.environ.get("SITRK_DEVICE", str(local_rank)))
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    red_dev = "cuda" if backend == "nccl" else "cpu"        # where the small reduction tensors live
 
     Nj, Ni, nP, label = CONFIGS[a.config]
     K = a.records
@@ -122,7 +130,7 @@ def main():
     _, yx = syn.make_buoys(grid, nP, seed=1234 + rank, frac=0.6)
     ji = syn.regular_host_cell(grid, yx).astype(np.int32)
 
-    ctx = sit.Context(local_rank)
+    ctx = sit.Context(dev)
     ctx.set_grid(grid["Yf"], grid["Xf"], grid["Yu"], grid["Xu"], grid["Yv"], grid["Xv"], grid["tmask"])
     ctx.set_params(3600., a.uv_strategy, 0.1)
     ctx.alloc_records(K, np.float32)
@@ -142,8 +150,11 @@ def main():
         slabs_host = [sd.pack_slab(u[k], v[k], sic[k], np.float32) for k in range(K)]
     if a.regime == "resident":
         for k in range(K):
-            if world > 1:
+            if world > 1 and backend == "nccl":
                 sd.broadcast_record(ctx, k, slabs_host[k] if rank == 0 else None, src=0)
+            elif world > 1:
+                slab = sd.broadcast_record_host(slabs_host[k] if rank == 0 else None, ctx.slab_elems, np.float32, src=0)
+                ctx.push_record(k, *sd.split_slab(slab, Nj, Ni))
             else:
                 ctx.push_record(k, u[k], v[k], sic[k])
 
@@ -186,6 +197,7 @@ def main():
         # end-to-end: record s goes pinned host -> slot s%2 on a copy stream (rank 0), is broadcast, and is
         # consumed by step s on the compute stream; delivery of record s+1 overlaps step s.
         assert K >= 2
+        assert world == 1 or backend == "nccl", "the e2e regime broadcasts device slabs: needs RCCL"
         comp, copy = torch.cuda.Stream(), torch.cuda.Stream()
         ctx.set_stream(comp.cuda_stream)
         slots = [sd.slot_tensor(ctx, 0), sd.slot_tensor(ctx, 1)]
@@ -225,13 +237,13 @@ def main():
         dt = time.perf_counter() - t0
         ctx.set_stream(None)
     if dist is not None:
-        t = torch.tensor([dt, ev_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, ev_ms], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, ev_ms = float(t[0]), float(t[1])
 
     nalive = ctx.count_alive()
     if dist is not None:
-        t = torch.tensor([nalive], dtype=torch.int64, device="cuda")
+        t = torch.tensor([nalive], dtype=torch.int64, device=red_dev)
         dist.all_reduce(t)
         nalive = int(t[0])
 

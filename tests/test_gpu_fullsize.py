@@ -1,0 +1,67 @@
+"""Parity at BASELINE.json's full C3 size (4096x4096 grid, 1e7 buoys) through size-independent properties:
+independence of the buoys (any partition of the set gives the same trajectories), equivalence of the fused
+multi-record launches with record-by-record stepping, invariance under the internal cell sort, plus the oracle
+on a subsample that the CPU finishes in seconds."""
+import numpy as np
+import pytest
+
+import sitrack_amd as sit
+from sitrack_amd import synthetic as syn
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c3():
+    N, nP, K = 4096, 10_000_000, 4
+    grid = syn.make_grid(N, N, dkm=4.0, warp=0.0)
+    u, v, sic = syn.make_fields(grid, K=K, seed=2024, umax=0.3, drift=0.05)
+    sic[:, 1500:1600, 1500:1700] = 0.02            # some open water so that buoys die
+    _, yx = syn.make_buoys(grid, nP, seed=1234, frac=0.6)
+    ji = syn.regular_host_cell(grid, yx).astype(np.int32)
+    return dict(grid=grid, u=u, v=v, sic=sic, yx=yx, ji=ji, K=K)
+
+
+def run(c3, sel, nsteps, **knobs):
+    g = c3["grid"]
+    ctx = sit.Context(0)
+    ctx.set_grid(g["Yf"], g["Xf"], g["Yu"], g["Xu"], g["Yv"], g["Xv"], g["tmask"])
+    ctx.alloc_records(c3["K"], np.float32)
+    for k in range(c3["K"]):
+        ctx.push_record(k, c3["u"][k], c3["v"][k], c3["sic"][k])
+    sort = knobs.pop("sort", True)
+    ctx.set_tuning(**knobs)
+    ctx.set_buoys(c3["yx"][sel], c3["ji"][sel], sort=sort)
+    ctx.run(0, 0, nsteps)
+    out = ctx.fetch()
+    ctx.close()
+    return out
+
+
+def test_full_size_properties(c3):
+    nP = len(c3["yx"])
+    nsteps = 24
+    whole = run(c3, slice(None), nsteps)                           # fused launches, tile-major sort
+    # (1) fused == record by record
+    single = run(c3, slice(None), nsteps, fuse=1)
+    for k in ("yx", "jiT", "alive", "kill_rec"):
+        assert np.array_equal(whole[k], single[k]), k
+    # (2) independence: two halves processed separately == the whole set (what the multi-GPU partition relies on)
+    h = nP // 2
+    lo, hi = run(c3, slice(0, h), nsteps), run(c3, slice(h, nP), nsteps)
+    for k in ("yx", "jiT", "alive", "kill_rec"):
+        assert np.array_equal(np.concatenate([lo[k], hi[k]]), whole[k]), k
+    # (3) the internal order does not matter: unsorted, row-major key
+    plain = run(c3, slice(None), nsteps, sort=False, sort_tile=0, fuse=3)
+    assert np.array_equal(plain["yx"], whole["yx"]) and np.array_equal(plain["jiT"], whole["jiT"])
+    # (4) checksum of checksums: outputs are in the caller's order, IDs never move
+    assert whole["alive"].sum() < nP and (whole["kill_rec"] >= 0).sum() == nP - whole["alive"].sum()
+    # (5) the oracle on a subsample spread over the whole set
+    sel = np.arange(0, nP, 997)
+    ref = orc.Tracker(c3["grid"], c3["yx"][sel], c3["ji"][sel], nthreads=8)
+    f64 = [(c3["u"][k].astype(np.float64), c3["v"][k].astype(np.float64), c3["sic"][k].astype(np.float64)) for k in range(c3["K"])]
+    for s in range(nsteps):
+        ref.step(s, *f64[s % c3["K"]], want_out=False)
+    assert np.array_equal(whole["yx"][sel], ref.pos)
+    assert np.array_equal(whole["jiT"][sel], ref.jiT) and np.array_equal(whole["alive"][sel], ref.alive)
