@@ -3,8 +3,11 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one model record applied to every buoy of the batch (one launch of
-advect_step_kernel per rank).  Workload at N=1 = BASELINE.json configs[2] (C3,
+A "step" is one model record applied to every buoy of the batch.  By default
+`sitrk_run` advances 8 resident records per launch (advect_run_kernel: loop
+interchange, every buoy still takes every step; `--fuse 1` = one launch of
+advect_step_kernel per record, also timed in the same run and reported under
+`per_record_launch`).  Workload at N=1 = BASELINE.json configs[2] (C3,
 the one the metric is quoted on): synthetic regular 4096x4096 C-grid (4 km),
 1e7 random buoys in the central 60 %, 8 device-resident fp32 records (solid-body
 rotation + per-record drift) cycled.  N>1: one process per GPU,
@@ -13,8 +16,8 @@ the record slabs are generated on rank 0 and broadcast over RCCL into every
 rank's resident slots (the path's only exchange step); stepping needs no
 collective.
 
-Prints ONE JSON line (rank 0).  `roofline.achieved` = ALGORITHMIC bytes per step
-over the average step duration measured with HIP events on the library's own
+Prints ONE JSON line (rank 0).  `roofline.achieved` = ALGORITHMIC bytes per launch
+over the average launch duration measured with HIP events on the library's own
 stream.  Algorithmic bytes follow SURVEY.md 8(d) -- 50 B of state per buoy + 56 B
 (48 B geometry + u,v) per grid cell the step needs -- but count only the cells the
 buoys' 2x2 stencils actually touch (the buoys fill the central 60 % of the domain):
