@@ -48,6 +48,10 @@ _SIGNATURES = {
     "sitrk_count_alive": (_int, [_vp, C.POINTER(_i64)]),
     "sitrk_find_cells": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "sitrk_seed_init": (_int, [_vp, _i64] + [_vp] * 9),
+    "sitrk_eval_inside": (_int, [_vp, _i64, _vp, _vp, _vp]),
+    "sitrk_eval_intersect": (_int, [_vp, _i64, _vp, _vp, _vp]),
+    "sitrk_eval_crossing": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "sitrk_survive_mask": (_int, [_vp, _vp, _vp]),
     "sitrk_cart2geo": (_int, [_vp, _i64, _vp, _dbl, _dbl, _vp]),
     "sitrk_geo2cart": (_int, [_vp, _i64, _vp, _dbl, _dbl, _vp]),
     "sitrk_timer_start": (_int, [_vp]),
@@ -282,6 +286,39 @@ class Context:
         self._chk(self._L.sitrk_seed_init(self._h, nP, _ptr(latlon), _ptr(yx), _ptr(latT), _ptr(lonT), _ptr(res), _ptr(sic),
                                           _ptr(jiT), _ptr(keep), _ptr(why)))
         return jiT, keep, why
+
+    # -- predicate probes (parity tests)
+    def eval_inside(self, pts, quads):
+        pts = as_c(pts, np.float64)
+        n = pts.shape[0]
+        quads = as_c(quads, np.float64, (n, 4, 2), "quads")
+        out = np.empty(n, dtype=np.int8)
+        self._chk(self._L.sitrk_eval_inside(self._h, n, _ptr(pts), _ptr(quads), _ptr(out)))
+        return out.astype(bool)
+
+    def eval_intersect(self, segs):
+        segs = as_c(segs, np.float64)
+        n = segs.shape[0]
+        segs = as_c(segs, np.float64, (n, 4, 2), "segs")
+        inter = np.empty(n, dtype=np.int8)
+        ccw = np.empty(n, dtype=np.int8)
+        self._chk(self._L.sitrk_eval_intersect(self._h, n, _ptr(segs), _ptr(inter), _ptr(ccw)))
+        return inter.astype(bool), ccw.astype(bool)
+
+    def eval_crossing(self, P1, P2, jiT):
+        P1 = as_c(P1, np.float64)
+        n = P1.shape[0]
+        P2 = as_c(P2, np.float64, (n, 2), "P2")
+        ji = as_c(jiT, np.int32, (n, 2), "jiT")
+        out = np.empty((n, 2), dtype=np.int32)
+        self._chk(self._L.sitrk_eval_crossing(self._h, n, _ptr(P1), _ptr(P2), _ptr(ji), _ptr(out)))
+        return out
+
+    def survive_mask(self, sic):
+        sic = as_c(sic, np.float64, (self.Nj, self.Ni), "sic")
+        out = np.empty((self.Nj, self.Ni), dtype=np.int8)
+        self._chk(self._L.sitrk_survive_mask(self._h, _ptr(sic), _ptr(out)))
+        return out
 
     def cart2geo(self, yx, lat0=70., lon0=-45.):
         yx = as_c(yx, np.float64)

@@ -703,6 +703,100 @@ SITRK_API int sitrk_seed_init(sitrk_t *h, int64_t nP, const double *latlon, cons
     return SITRK_OK;
 }
 
+// --------------------------------------------------------------------------- predicate probes
+SITRK_API int sitrk_eval_inside(sitrk_t *h, int64_t n, const double *pts, const double *quads, int8_t *inside)
+{
+    NEED(h, "null handle");
+    NEED(n >= 0, "sitrk_eval_inside: n < 0");
+    if (n == 0) return SITRK_OK;
+    NEED(pts && quads && inside, "sitrk_eval_inside: null array");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t b_p = align256((size_t)n * sizeof(pt)), b_q = align256((size_t)n * 4 * sizeof(pt)), b_o = align256((size_t)n);
+    int rc = ensure_scratch(h, b_p + b_q + b_o);
+    if (rc) return rc;
+    char *s = (char *)h->scratch;
+    HIPCHK(hipMemcpyAsync(s, pts, (size_t)n * sizeof(pt), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(s + b_p, quads, (size_t)n * 4 * sizeof(pt), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(eval_inside_kernel, dim3(nblocks(n)), dim3(kBlock), 0, h->stream, n, (const pt *)s, (const pt *)(s + b_p),
+                       (int8_t *)(s + b_p + b_q));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(inside, s + b_p + b_q, (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SITRK_OK;
+}
+
+SITRK_API int sitrk_eval_intersect(sitrk_t *h, int64_t n, const double *segs, int8_t *intersect, int8_t *ccw_abc)
+{
+    NEED(h, "null handle");
+    NEED(n >= 0, "sitrk_eval_intersect: n < 0");
+    if (n == 0) return SITRK_OK;
+    NEED(segs && intersect, "sitrk_eval_intersect: null array");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t b_s = align256((size_t)n * 4 * sizeof(pt)), b_o = align256((size_t)n);
+    int rc = ensure_scratch(h, b_s + 2 * b_o);
+    if (rc) return rc;
+    char *s = (char *)h->scratch;
+    HIPCHK(hipMemcpyAsync(s, segs, (size_t)n * 4 * sizeof(pt), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(eval_intersect_kernel, dim3(nblocks(n)), dim3(kBlock), 0, h->stream, n, (const pt *)s, (int8_t *)(s + b_s),
+                       ccw_abc ? (int8_t *)(s + b_s + b_o) : nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(intersect, s + b_s, (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    if (ccw_abc) HIPCHK(hipMemcpyAsync(ccw_abc, s + b_s + b_o, (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SITRK_OK;
+}
+
+SITRK_API int sitrk_eval_crossing(sitrk_t *h, int64_t n, const double *P1, const double *P2, const int32_t *jiT, int32_t *jiT_new)
+{
+    NEED(h, "null handle");
+    NEED(h->geo, "sitrk_eval_crossing: call sitrk_set_grid first");
+    NEED(n >= 0, "sitrk_eval_crossing: n < 0");
+    if (n == 0) return SITRK_OK;
+    NEED(P1 && P2 && jiT && jiT_new, "sitrk_eval_crossing: null array");
+    for (int64_t p = 0; p < n; p++)
+        if (jiT[2 * p] < 1 || jiT[2 * p] > h->Nj - 2 || jiT[2 * p + 1] < 1 || jiT[2 * p + 1] > h->Ni - 2)
+            return fail(h, SITRK_EINDEX, "sitrk_eval_crossing: host cell (%d,%d) outside 1..%d x 1..%d", jiT[2 * p], jiT[2 * p + 1],
+                        h->Nj - 2, h->Ni - 2);
+    HIPCHK(hipSetDevice(h->device));
+    const size_t cells = (size_t)h->Nj * h->Ni;
+    const size_t b_p = align256((size_t)n * sizeof(pt)), b_j = align256((size_t)n * 8), b_m = align256(cells);
+    int rc = ensure_scratch(h, 2 * b_p + 2 * b_j + b_m);
+    if (rc) return rc;
+    char *s = (char *)h->scratch;
+    pt *d1 = (pt *)s, *d2 = (pt *)(s + b_p);
+    int32_t *dj = (int32_t *)(s + 2 * b_p), *dn = (int32_t *)(s + 2 * b_p + b_j);
+    int8_t *zero = (int8_t *)(s + 2 * b_p + 2 * b_j);
+    HIPCHK(hipMemcpyAsync(d1, P1, (size_t)n * sizeof(pt), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d2, P2, (size_t)n * sizeof(pt), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dj, jiT, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(zero, 0, cells, h->stream));
+    hipLaunchKernelGGL(eval_crossing_kernel, dim3(nblocks(n)), dim3(kBlock), 0, h->stream, n, h->Nj, h->Ni, h->geo, zero, d1, d2, dj, dn);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(jiT_new, dn, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SITRK_OK;
+}
+
+SITRK_API int sitrk_survive_mask(sitrk_t *h, const double *sic, int8_t *mask)
+{
+    NEED(h, "null handle");
+    NEED(h->geo, "sitrk_survive_mask: call sitrk_set_grid first");
+    NEED(sic && mask, "sitrk_survive_mask: null array");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t cells = (size_t)h->Nj * h->Ni;
+    const size_t b_s = align256(cells * 8), b_m = align256(cells);
+    int rc = ensure_scratch(h, b_s + b_m);
+    if (rc) return rc;
+    char *s = (char *)h->scratch;
+    HIPCHK(hipMemcpyAsync(s, sic, cells * 8, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL((survive_mask_kernel<double>), dim3(nblocks((int64_t)cells)), dim3(kBlock), 0, h->stream, h->Nj, h->Ni, h->tmask,
+                       (const double *)s, h->rmin_conc, (int8_t *)(s + b_s));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(mask, s + b_s, cells, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SITRK_OK;
+}
+
 // --------------------------------------------------------------------------- projection
 static int project(sitrk_ctx *h, int64_t n, const double *in, double lat0, double lon0, double *out, bool inverse)
 {

@@ -345,6 +345,41 @@ __global__ __launch_bounds__(kBlock) void advect_nocross_kernel(StepArgs a)
 #endif  // SITRK_DIAG
 
 // ---------------------------------------------------------------------------
+// Predicate probes: the device functions of the hot path evaluated on plain arrays, so that the parity
+// tests can hold them against the reference's golden vectors one predicate at a time (sitrk_eval_*).
+// ---------------------------------------------------------------------------
+__global__ void eval_inside_kernel(int64_t n, const pt *__restrict__ pts, const pt *__restrict__ quads, int8_t *__restrict__ out)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    out[k] = inside_quad(pts[k].y, pts[k].x, quads[4 * k], quads[4 * k + 1], quads[4 * k + 2], quads[4 * k + 3]) ? 1 : 0;
+}
+
+__global__ void eval_intersect_kernel(int64_t n, const pt *__restrict__ segs, int8_t *__restrict__ inter, int8_t *__restrict__ ccw_abc)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const pt A = segs[4 * k], B = segs[4 * k + 1], Cc = segs[4 * k + 2], D = segs[4 * k + 3];
+    inter[k] = intersect2seg(A, B, Cc, D) ? 1 : 0;
+    if (ccw_abc) ccw_abc[k] = ccw(A, B, Cc) ? 1 : 0;
+}
+
+__global__ void eval_crossing_kernel(int64_t n, int Nj, int Ni, const CellGeo *__restrict__ geo, const int8_t *__restrict__ zero_mask,
+                                     const pt *__restrict__ P1, const pt *__restrict__ P2, const int32_t *__restrict__ jiT,
+                                     int32_t *__restrict__ jiT_new)
+{
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int jT = jiT[2 * p], iT = jiT[2 * p + 1];
+    const size_t k = (size_t)jT * Ni + iT;
+    bool killed;
+    const int32_t cn = resolve_crossing(P1[p], P2[p], geo[k - Ni - 1].f, geo[k - Ni].f, geo[k].f, geo[k - 1].f, jT, iT, Nj, Ni, geo,
+                                        zero_mask, killed);
+    jiT_new[2 * p] = cell_j(cn);
+    jiT_new[2 * p + 1] = cell_i(cn);
+}
+
+// ---------------------------------------------------------------------------
 // state upload helpers / sort support
 // ---------------------------------------------------------------------------
 __global__ void iota_kernel(int64_t n, int32_t *v)

@@ -24,6 +24,42 @@ def make_tracker(grid, tmask, nslots, **kw):
                           nslots=nslots, **kw)
 
 
+def test_g1_is_inside_quadrangle_on_device(golden, ctx):
+    g = golden("g1_inside.npz")
+    got = ctx.eval_inside(g["pts"], g["quads"])
+    assert list(got[:4]) == [True, False, False, True]          # reference tools/tests/test_pnt_inside_quad.py:16-24
+    assert np.array_equal(got, g["inside"])
+
+
+def test_g2_intersect2seg_and_ccw_on_device(golden, ctx):
+    g = golden("g2_intersect.npz")
+    inter, ccw = ctx.eval_intersect(g["P"])
+    assert np.array_equal(inter, g["intersect"]) and np.array_equal(ccw, g["ccw"])
+
+
+def test_g3_crossing_chain_on_device(golden, ctx):
+    g = golden("g3_crossing.npz")
+    Nj, Ni = g["Yf"].shape
+    ctx.set_grid(g["Yf"], g["Xf"], g["Yf"], g["Xf"], g["Yf"], g["Xf"], np.ones((Nj, Ni), dtype=np.int8))
+    got = ctx.eval_crossing(g["P1"], g["P2"], g["jiT"])
+    assert np.array_equal(got, g["jiT_out"])
+    assert set(np.unique(g["inhc"])) == set(range(1, 9))
+    with pytest.raises(IndexError):
+        ctx.eval_crossing(g["P1"][:1], g["P2"][:1], np.array([[0, 3]]))
+
+
+def test_g4_survive_on_device(golden, ctx):
+    g = golden("g4_survive.npz")
+    Nj, Ni = g["tmask"].shape
+    z = np.zeros((Nj, Ni))
+    for tm, sic, key in ((g["tmask"], g["sic"], "kill_a"), (g["tmask"], g["sic32"].astype(np.float64), "kill_b"),
+                         (np.ones_like(g["tmask"]), g["sic32"].astype(np.float64), "kill_c")):
+        ctx.set_grid(z, z, z, z, z, z, tm)
+        ctx.set_params(3600., 1, 0.1)
+        mask = ctx.survive_mask(sic)
+        assert np.array_equal(mask.ravel(), g[key].astype(np.int8)), key     # jiT in G4 enumerates the grid in C order
+
+
 @pytest.mark.parametrize("tag", ["curvi", "regular"])
 @pytest.mark.parametrize("strat", [1, 0])
 @pytest.mark.parametrize("sort", [True, False])
