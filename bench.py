@@ -254,9 +254,13 @@ def main():
         from oracle import oracle as orc
         nS = 20000
         ref = orc.Tracker(grid, yx[:nS], ji[:nS], uv_strategy=a.uv_strategy, nthreads=8)
-        for s in range((a.warmup + a.steps) if per_record is None else (a.warmup + 2 * a.steps)):
-            k = s % K
-            ref.step(s, u[k].astype(np.float64), v[k].astype(np.float64), sic[k].astype(np.float64), want_out=False)
+        f64 = [(u[k].astype(np.float64), v[k].astype(np.float64), sic[k].astype(np.float64)) for k in range(K)]
+        nchk = (a.warmup + a.steps) if per_record is None else (a.warmup + 2 * a.steps)
+        for s in range(nchk):
+            ref.step(s, *f64[s % K], want_out=False)
+            if s % 2000 == 1999:
+                print("check: oracle at step %d / %d" % (s + 1, nchk), file=sys.stderr, flush=True)
+        del f64
         st = ctx.fetch()
         assert np.array_equal(st["yx"][:nS], ref.pos) and np.array_equal(st["jiT"][:nS], ref.jiT)
         assert np.array_equal(st["alive"][:nS], ref.alive)
