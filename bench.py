@@ -284,12 +284,14 @@ def main():
         launch_s = (ev_ms / 1e3) / nlaunch
         achieved = A / launch_s / 1e9
         traffic = traffic_fused = None
+        prof_fused = {}
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tj):
             try:
                 tjd = json.load(open(tj))
                 traffic = tjd.get(a.config, {}).get("hbm_bytes_per_launch")
                 traffic_fused = tjd.get(a.config + "_fused", {}).get("hbm_bytes_per_launch")
+                prof_fused = tjd.get(a.config + "_fused", {})
             except Exception:
                 traffic = None
         line = {
@@ -310,6 +312,8 @@ def main():
                          "note": ("%d records per launch: state and geometry are read once per launch, so the kernel is "
                                   "fp64-issue bound, not HBM bound; see per_record_launch for the HBM-bound form" % fuse)
                          if fuse > 1 else "one record per launch",
+                         "valu_busy_frac_profiled": prof_fused.get("valu_busy_frac") if fuse > 1 else None,
+                         "sclk_ghz_profiled": prof_fused.get("sclk_ghz") if fuse > 1 else None,
                          "survey_formula_bytes_per_record": A_survey,
                          "survey_formula_frac_per_record": A_survey / step_s / 1e9 / HBM_PEAK_GBS},
         }

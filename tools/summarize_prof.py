@@ -82,6 +82,16 @@ def main():
         for c in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum", "TCC_HIT_sum", "TCC_MISS_sum"):
             if c in a:
                 res[c] = a[c]
+        if "SQ_ACTIVE_INST_VALU" in a and "GRBM_GUI_ACTIVE" in a and res.get("avg_kernel_us"):
+            # SQ_* count quad-cycles summed over waves; 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+            cyc = a["GRBM_GUI_ACTIVE"] / 8.0
+            res["sclk_ghz"] = cyc / (res["avg_kernel_us"] * 1e3)
+            res["valu_busy_frac"] = a["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / cyc
+            if "SQ_INSTS_VALU" in a and "SQ_WAVES" in a:
+                res["valu_insts_per_wave"] = a["SQ_INSTS_VALU"] / a["SQ_WAVES"]
+            lines.append("Instruction issue: SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs = %.0f cycles per SIMD of %.0f available "
+                         "(GRBM_GUI_ACTIVE / 8) -> VALU busy %.0f %%; clock held %.2f GHz."
+                         % (a["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0, cyc, 100 * res["valu_busy_frac"], res["sclk_ghz"]))
         if "TCC_HIT_sum" in a and "TCC_MISS_sum" in a:
             lines.append("L2 hit rate TCC_HIT/(HIT+MISS) = %.3f." % (a["TCC_HIT_sum"] / (a["TCC_HIT_sum"] + a["TCC_MISS_sum"])))
     bg = next((k for k in avg if "build_geo_kernel" in k), None)
@@ -102,7 +112,8 @@ def main():
     tj = os.path.join(root, "profiles", "traffic.json")
     allt = json.load(open(tj)) if os.path.exists(tj) else {}
     if "hbm_bytes_per_launch" in res:
-        allt[config + "_fused" if fused else config] = {"hbm_bytes_per_launch": res["hbm_bytes_per_launch"], "source": os.path.basename(out_md)}
+        allt[config + "_fused" if fused else config] = {"hbm_bytes_per_launch": res["hbm_bytes_per_launch"], "source": os.path.basename(out_md),
+                                                        "valu_busy_frac": res.get("valu_busy_frac"), "sclk_ghz": res.get("sclk_ghz")}
         json.dump(allt, open(tj, "w"), indent=1)
     print("\n".join(lines))
 
