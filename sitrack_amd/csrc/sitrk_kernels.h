@@ -256,8 +256,36 @@ struct RunArgs {
     const int8_t *kill[kMaxFuse];
 };
 
+// ---------------------------------------------------------------------------
+// The fused kernel keeps the HOST CELL'S CONTEXT in registers across records: the 8 geometry points and
+// the two record-independent orientation terms of the velocity pick (ccw(F,V01,V11), ccw(F,U10,U11)) are
+// (re)loaded only when the buoy changes cell (3-16 % of the records); per record only the four velocity
+// candidates are loaded.  Same operations on the same operands in the same order as advance_record.
+// 91 VGPRs -> 5 waves/SIMD: the kernel is bound by fp64 issue, not by latency (-5 % vs reloading the
+// geometry every record at 8 waves/SIMD; requesting the next record's velocities one record ahead was
+// measured 7 % slower: more instructions in an issue-bound loop).
+// ---------------------------------------------------------------------------
+struct CellCtx {
+    size_t k;
+    pt F11, U11, V11, F10, U10, F01, V01, F00;
+    bool sFV, sFU;                      // ccw(F11,V01,V11), ccw(F11,U10,U11)
+};
+
+__device__ __forceinline__ void load_ctx(const StepArgs &a, int32_t c, CellCtx &x)
+{
+    const int Ni = a.Ni;
+    x.k = (size_t)cell_j(c) * Ni + cell_i(c);
+    const CellGeo g11 = a.geo[x.k];
+    x.F11 = g11.f; x.U11 = g11.u; x.V11 = g11.v;
+    x.F10 = a.geo[x.k - 1].f; x.U10 = a.geo[x.k - 1].u;
+    x.F01 = a.geo[x.k - Ni].f; x.V01 = a.geo[x.k - Ni].v;
+    x.F00 = a.geo[x.k - Ni - 1].f;
+    x.sFV = ccw(x.F11, x.V01, x.V11);
+    x.sFU = ccw(x.F11, x.U10, x.U11);
+}
+
 template <typename FT, int UVS, bool WINDOW>
-__global__ __launch_bounds__(kBlock, 8) void advect_run_kernel(RunArgs ra)
+__global__ __launch_bounds__(kBlock, 5) void advect_run_kernel(RunArgs ra)
 {
     const StepArgs &a = ra.s;
     const unsigned blk = (a.tune & TUNE_XCD_REMAP) ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
@@ -265,12 +293,15 @@ __global__ __launch_bounds__(kBlock, 8) void advect_run_kernel(RunArgs ra)
     if (p >= a.nP) return;
     const bool nt = (a.tune & TUNE_NT_STATE) != 0;
     int32_t c = nt ? __builtin_nontemporal_load(&a.cell[p]) : a.cell[p];
-    if (c < 0) return;
+    if (c < 0) return;                                   // iAlive != 1 (:380)
     int first = 0, last = 0x7fffffff;
     if (WINDOW) { first = a.first[p]; last = a.last[p]; }
     pt P = nt ? load_pt_nt(&a.pos[p]) : a.pos[p];
     const int32_t c0 = c;
+    const int Ni = a.Ni, Nj = a.Nj;
     bool moved = false;
+    CellCtx x;
+    load_ctx(a, c, x);
 #pragma unroll 1
     for (int r = 0; r < ra.nrec; r++) {
         const int jrec = a.jrec + r;
@@ -278,8 +309,34 @@ __global__ __launch_bounds__(kBlock, 8) void advect_run_kernel(RunArgs ra)
             if (jrec < first) continue;
             if (jrec > last) break;
         }
+        const FT *__restrict__ u = (const FT *)ra.u[r];
+        const FT *__restrict__ v = (const FT *)ra.v[r];
+        double zU, zV;
+        if (UVS == 0) {                                  // :423-425
+            zU = 0.5 * ((double)u[x.k] + (double)u[x.k - 1]);
+            zV = 0.5 * ((double)v[x.k] + (double)v[x.k - Ni]);
+        } else {                                         // :427-441
+            const double u1 = (double)u[x.k], u0 = (double)u[x.k - 1];
+            const double v1 = (double)v[x.k], v0 = (double)v[x.k - Ni];
+            // intersect2Seg(P,F,C,D) = (ccw(P,C,D) != ccw(F,C,D)) and (ccw(P,F,C) != ccw(P,F,D)); ccw(F,C,D) is per cell
+            const bool llum1 = (ccw(P, x.V01, x.V11) != x.sFV) && (ccw(P, x.F11, x.V01) != ccw(P, x.F11, x.V11));
+            const bool llvm1 = (ccw(P, x.U10, x.U11) != x.sFU) && (ccw(P, x.F11, x.U10) != ccw(P, x.F11, x.U11));
+            zU = llum1 ? u0 : u1;
+            zV = llvm1 ? v0 : v1;
+        }
+        const double dx = zU * a.rdt;                    // :452-458
+        const double dy = zV * a.rdt;
+        pt Pn;
+        Pn.x = P.x + dx / 1000.;
+        Pn.y = P.y + dy / 1000.;
         moved = true;
-        if (!advance_record<FT, UVS>(a, (const FT *)ra.u[r], (const FT *)ra.v[r], ra.kill[r], P, c)) {
+        bool killed = false;
+        if (!inside_quad(Pn.y, Pn.x, x.F00, x.F01, x.F11, x.F10)) {      // :466-484
+            c = resolve_crossing(P, Pn, x.F00, x.F01, x.F11, x.F10, cell_j(c), cell_i(c), Nj, Ni, a.geo, ra.kill[r], killed);
+            if (!killed) load_ctx(a, c, x);
+        }
+        P = Pn;
+        if (killed) {
             a.kill_rec[p] = jrec;
             break;                                       // dead buoys never step again
         }
