@@ -1,11 +1,13 @@
 // sitrk_kernels.h -- HIP kernels of libsitrk.so (gfx950, wave64).
 //
-// advect_step_kernel is the hot path: one buoy per lane, buoys kept sorted by
-// host cell so that a wavefront's gathers fall on a few contiguous 48-byte cell
-// records (F,U,V plane coordinates interleaved) and on short runs of the u/v
-// slabs.  The work is HBM/latency bound (~100 fp64 flops vs ~140 B per
-// particle-step): no LDS reuse to exploit beyond what L1/L2 already give for
-// sorted buoys, no MFMA.
+// The hot path is advance_record(): everything one buoy does for one model record, one buoy per
+// lane.  Buoys are kept sorted by host cell (tile-major), so a wavefront's gathers fall on a few
+// contiguous 48-byte cell records (F,U,V plane coordinates interleaved) and short runs of the u/v
+// slabs; L1/L2 coalesce them, there is no cross-lane reuse left for LDS to exploit, and nothing is a
+// contraction (no MFMA).  Two launch forms:
+//   advect_step_kernel : one record per launch  -- HBM bound (~84 B and ~250 fp64-issue slots per particle-step)
+//   advect_run_kernel  : up to 8 resident records per launch, buoy and cell context in registers -- fp64-issue bound
+// Measurements and the optimisation history are in DESIGN.md section 3.2.
 #pragma once
 #include "sitrk_internal.h"
 
