@@ -58,7 +58,7 @@ def lib():
         L.orc_nearest_point.restype = None
         L.orc_find_containing_cell.argtypes = [_dbl, _dbl, _i64, _i64, _f64p, _f64p, _i64, _i64, _i64p, _i64p]
         L.orc_seed_init.argtypes = [_i64, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _i8p, _f64p,
-                                    _i64, _i64, _dbl, _dbl, _int, _i64p, _i64p, _i8p, _i8p]
+                                    _i64, _i64, _dbl, _dbl, _int, _i64p, _i64p, _i8p, _i8p, _int]
         L.orc_advect_record.argtypes = [_i64, _i64, _dbl, _int, _dbl, _i64, _i64,
                                         _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _i8p,
                                         _f64p, _f64p, _f64p, _i64p, _i64p,
@@ -153,7 +153,7 @@ def FindContainingCell(pyx, kjiT, Yf, Xf):
     return bool(st), jiT, vert
 
 
-def SeedInit(pIDs, pSG, pSC, latT, lonT, Yf, Xf, resolkm, tmask, sic, return_why=False):
+def SeedInit(pIDs, pSG, pSC, latT, lonT, Yf, Xf, resolkm, tmask, sic, return_why=False, nthreads=1):
     """Same return tuple as the reference (tracking.py:178)."""
     nP = pSG.shape[0]
     Nj, Ni = latT.shape
@@ -166,7 +166,7 @@ def SeedInit(pIDs, pSG, pSC, latT, lonT, Yf, Xf, resolkm, tmask, sic, return_why
     _chk(lib().orc_seed_init(nP, pSG.reshape(-1), pSC.reshape(-1), latT, lonT, Yf, Xf,
                              np.ascontiguousarray(resolkm, dtype=np.float64), tmask,
                              np.ascontiguousarray(sic, dtype=np.float64), Nj, Ni,
-                             rmin_conc, rFoundKM, 10, jiT.reshape(-1), vert.reshape(-1), keep, why), "SeedInit")
+                             rmin_conc, rFoundKM, 10, jiT.reshape(-1), vert.reshape(-1), keep, why, int(nthreads)), "SeedInit")
     iKeep = np.where(keep == 1)[0]
     out = (len(iKeep), pSG[iKeep, :], pSC[iKeep, :], np.asarray(pIDs)[iKeep], jiT[iKeep, :], vert[iKeep, :, :], iKeep)
     return out + (why,) if return_why else out

@@ -300,8 +300,13 @@ int orc_seed_init(i64 nP, const double *pSG, const double *pSC,
                   const double *latT, const double *lonT, const double *Yf, const double *Xf,
                   const double *resol, const int8_t *tmask, const double *sic,
                   i64 Nj, i64 Ni, double rmin_conc, double rd_found_km, int max_itr,
-                  i64 *jiT, i64 *vert, int8_t *keep, int8_t *why)
+                  i64 *jiT, i64 *vert, int8_t *keep, int8_t *why, int nthreads)
 {
+    int status = ORC_OK;
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1) reduction(min:status)
+#endif
     for (i64 p = 0; p < nP; p++) {
         i64 jT, iT;
         keep[p] = 1;
@@ -312,14 +317,14 @@ int orc_seed_init(i64 nP, const double *pSG, const double *pSC,
                           rd_found_km, max_itr, &jT, &iT, NULL);
         if (jT < 0 || iT < 0) { keep[p] = 0; if (why) why[p] = 1; continue; }
         int ic = orc_survive(jT, iT, tmask, sic, Nj, Ni, rmin_conc, NULL);
-        if (ic < 0) return ic;
+        if (ic < 0) { if (ic < status) status = ic; continue; }
         if (ic > 0) { keep[p] = 0; if (why) why[p] = 2; continue; }
         int lPin = orc_find_containing_cell(pSC[2 * p], pSC[2 * p + 1], jT, iT, Yf, Xf, Nj, Ni,
                                             jiT + 2 * p, vert + 8 * p);
-        if (lPin < 0) return lPin;
+        if (lPin < 0) { if (lPin < status) status = lPin; continue; }
         if (!lPin) { keep[p] = 0; if (why) why[p] = 3; }
     }
-    return ORC_OK;
+    return status;
 }
 
 /* ------------------------------------------------------------------------
