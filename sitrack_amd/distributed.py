@@ -56,12 +56,44 @@ def broadcast_record(ctx, slot, slab_host, src=0, group=None, async_op=False):
     t = slot_tensor(ctx, slot)
     if dist.get_rank(group) == src:
         t.copy_(torch.from_numpy(slab_host), non_blocking=False)
-    work = dist.broadcast(t, src=src, group=group, async_op=async_op)
+    import os
+    if os.environ.get("SITRK_BCAST", "") == "scatter_allgather" and not async_op and dist.get_world_size(group) > 2:
+        scatter_allgather(t, src=src, group=group)
+        work = None
+    else:
+        work = dist.broadcast(t, src=src, group=group, async_op=async_op)
     if async_op:
         return work                    # caller: work.wait(), order the streams, then ctx.commit_record(slot)
     torch.cuda.current_stream().synchronize()
     ctx.commit_record(slot)            # derive the record's Survive mask from the new slab
     return None
+
+
+def scatter_allgather(t, src=0, group=None):
+    """Broadcast of the 1-D tensor `t` as scatter + all-gather: the root sends a different 1/N-th of the slab to every
+    rank and the ranks then exchange their pieces, so every xGMI link of the full mesh carries 1/N-th of the bytes
+    instead of one link carrying the whole slab (~2S/(7B) instead of S/B for a ring at N = 8).
+    Opt-in (env SITRK_BCAST=scatter_allgather): whether it beats RCCL's own broadcast is for the 8-GPU node to say.
+    Works with any backend; in place on every rank."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = t.numel()
+    chunk = (n + world - 1) // world
+    pad = chunk * world
+    buf = t if pad == n else torch.empty(pad, dtype=t.dtype, device=t.device)
+    if buf is not t and rank == src:
+        buf[:n].copy_(t)
+    pieces = [buf[r * chunk:(r + 1) * chunk] for r in range(world)]
+    mine = torch.empty(chunk, dtype=t.dtype, device=t.device)
+    dist.scatter(mine, scatter_list=pieces if rank == src else None, src=src, group=group)
+    if hasattr(dist, "all_gather_into_tensor") and t.is_cuda:
+        dist.all_gather_into_tensor(buf, mine, group=group)
+    else:
+        dist.all_gather(pieces, mine, group=group)
+    if buf is not t:
+        t.copy_(buf[:n])
+    return t
 
 
 def broadcast_record_host(slab_host, nelem, dtype, src=0, group=None):

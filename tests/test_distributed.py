@@ -79,6 +79,39 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _sag_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok = True
+        for n in (10, 3 * 7 * 11, 1000):                      # divisible and not divisible by the world size
+            want = torch.arange(n, dtype=torch.float32) * 0.5 + 1.0
+            t = want.clone() if rank == 1 else torch.full((n,), -7.0)
+            sd.scatter_allgather(t, src=1)
+            ok = ok and bool(torch.equal(t, want))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_scatter_allgather_equals_broadcast_world3():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sag_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(3)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r for r, _ in res) == [0, 1, 2] and all(ok for _, ok in res)
+
+
 def test_world2_gloo_partition_broadcast_gather():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
