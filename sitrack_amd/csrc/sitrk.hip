@@ -190,6 +190,11 @@ SITRK_API int sitrk_set_tuning(sitrk_t *h, const char *knob, int value)
     int bit = 0;
     if (!strcmp(knob, "xcd_remap")) bit = TUNE_XCD_REMAP;
     else if (!strcmp(knob, "nt_state")) bit = TUNE_NT_STATE;
+    else if (!strcmp(knob, "step_block")) {          // workgroup size of advect_step_kernel
+        if (value != 256 && value != 512 && value != 1024) return fail(h, SITRK_EINVAL, "sitrk_set_tuning: step_block must be 256, 512 or 1024");
+        h->step_block = value;
+        return SITRK_OK;
+    }
     else if (!strcmp(knob, "fuse")) {                // records per launch in sitrk_run (1..8)
         if (value < 1 || value > kMaxFuse) return fail(h, SITRK_EINVAL, "sitrk_set_tuning: fuse must be 1..%d", kMaxFuse);
         h->fuse = value;
@@ -392,26 +397,30 @@ SITRK_API int sitrk_sort_buoys(sitrk_t *h)
     return SITRK_OK;
 }
 
+template <typename FT, int BLOCK>
+static void launch_step_b(sitrk_ctx *h, const StepArgs &a)
+{
+    dim3 grid(nblocks(a.nP, BLOCK)), block(BLOCK);
+    if (h->uv_strategy == 1) {
+        if (h->windowed) hipLaunchKernelGGL((advect_step_kernel<FT, 1, true, BLOCK>), grid, block, 0, h->stream, a);
+        else hipLaunchKernelGGL((advect_step_kernel<FT, 1, false, BLOCK>), grid, block, 0, h->stream, a);
+    } else {
+        if (h->windowed) hipLaunchKernelGGL((advect_step_kernel<FT, 0, true, BLOCK>), grid, block, 0, h->stream, a);
+        else hipLaunchKernelGGL((advect_step_kernel<FT, 0, false, BLOCK>), grid, block, 0, h->stream, a);
+    }
+}
+
 template <typename FT>
 static void launch_step(sitrk_ctx *h, const StepArgs &a)
 {
-    dim3 grid(nblocks(a.nP)), block(kBlock);
-#define SITRK_LAUNCH(KERNEL)                                                                              \
-    do {                                                                                                  \
-        if (h->uv_strategy == 1) {                                                                        \
-            if (h->windowed) hipLaunchKernelGGL((KERNEL<FT, 1, true>), grid, block, 0, h->stream, a);     \
-            else hipLaunchKernelGGL((KERNEL<FT, 1, false>), grid, block, 0, h->stream, a);                \
-        } else {                                                                                          \
-            if (h->windowed) hipLaunchKernelGGL((KERNEL<FT, 0, true>), grid, block, 0, h->stream, a);     \
-            else hipLaunchKernelGGL((KERNEL<FT, 0, false>), grid, block, 0, h->stream, a);                \
-        }                                                                                                 \
-    } while (0)
 #ifdef SITRK_DIAG
+    dim3 grid(nblocks(a.nP)), block(kBlock);
     if (h->tune & TUNE_DIAG_MEMONLY) { hipLaunchKernelGGL((advect_memonly_kernel<FT>), grid, block, 0, h->stream, a); return; }
     if (h->tune & TUNE_DIAG_NOCROSS) { hipLaunchKernelGGL((advect_nocross_kernel<FT>), grid, block, 0, h->stream, a); return; }
 #endif
-    SITRK_LAUNCH(advect_step_kernel);
-#undef SITRK_LAUNCH
+    if (h->step_block == 1024) launch_step_b<FT, 1024>(h, a);
+    else if (h->step_block == 512) launch_step_b<FT, 512>(h, a);
+    else launch_step_b<FT, 256>(h, a);
 }
 
 SITRK_API int sitrk_step(sitrk_t *h, int slot, int jrec)

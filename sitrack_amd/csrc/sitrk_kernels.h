@@ -220,11 +220,11 @@ __device__ __forceinline__ bool advance_record(const StepArgs &a, const FT *__re
 // One model record for every buoy, one buoy per lane (sitrk_step).
 //   WINDOW : per-buoy first/last model record (2-D time mode, :264-318,380)
 // ---------------------------------------------------------------------------
-template <typename FT, int UVS, bool WINDOW>
-__global__ __launch_bounds__(kBlock, 8) void advect_step_kernel(StepArgs a)
+template <typename FT, int UVS, bool WINDOW, int BLOCK>
+__global__ __launch_bounds__(BLOCK, 8) void advect_step_kernel(StepArgs a)
 {
     const unsigned blk = (a.tune & TUNE_XCD_REMAP) ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
-    const int64_t p = (int64_t)blk * kBlock + threadIdx.x;
+    const int64_t p = (int64_t)blk * BLOCK + threadIdx.x;
     if (p >= a.nP) return;
     const bool nt = (a.tune & TUNE_NT_STATE) != 0;
     int32_t c = nt ? __builtin_nontemporal_load(&a.cell[p]) : a.cell[p];

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--knobs", default="xcd_remap,nt_state")
     ap.add_argument("--tiles", default="", help="comma list of tile_jxtile_i sort orders to add as variants, e.g. 8x32,16x16")
     ap.add_argument("--fuse", default="", help="comma list of records-per-launch values to add as variants, e.g. 2,4,8")
+    ap.add_argument("--values", default="", help="knob:v1:v2:... extra variants sweeping one knob's values, e.g. step_block:512:1024")
     ap.add_argument("--base", default="", help="knob=value,... applied to every variant")
     ap.add_argument("--singles", default="", help="extra variants, one knob each (e.g. diag_memonly,diag_nocross); no result check")
     a = ap.parse_args()
@@ -51,6 +52,10 @@ def main():
         variants.append(dict({k: 0 for k in allk}, sort_tile=tj * 256 + ti))
     for fz in [int(x) for x in a.fuse.split(",") if x]:
         variants.append(dict({k: 0 for k in allk}, sort_tile=8 * 256 + 16, fuse=fz))
+    if a.values:
+        kn, *vals = a.values.split(":")
+        for vv in vals:
+            variants.append({kn: int(vv)})
     variants = [dict(dict(fuse=1), **dict(v, **base)) for v in variants]
     times = {i: [] for i in range(len(variants))}
     ref = None
