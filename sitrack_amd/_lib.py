@@ -50,7 +50,7 @@ _SIGNATURES = {
     "sitrk_seed_init": (_int, [_vp, _i64] + [_vp] * 9),
     "sitrk_eval_inside": (_int, [_vp, _i64, _vp, _vp, _vp]),
     "sitrk_eval_intersect": (_int, [_vp, _i64, _vp, _vp, _vp]),
-    "sitrk_eval_crossing": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "sitrk_eval_crossing": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "sitrk_survive_mask": (_int, [_vp, _vp, _vp]),
     "sitrk_cart2geo": (_int, [_vp, _i64, _vp, _dbl, _dbl, _vp]),
     "sitrk_geo2cart": (_int, [_vp, _i64, _vp, _dbl, _dbl, _vp]),
@@ -311,8 +311,9 @@ class Context:
         P2 = as_c(P2, np.float64, (n, 2), "P2")
         ji = as_c(jiT, np.int32, (n, 2), "jiT")
         out = np.empty((n, 2), dtype=np.int32)
-        self._chk(self._L.sitrk_eval_crossing(self._h, n, _ptr(P1), _ptr(P2), _ptr(ji), _ptr(out)))
-        return out
+        codes = np.empty((n, 2), dtype=np.int32)
+        self._chk(self._L.sitrk_eval_crossing(self._h, n, _ptr(P1), _ptr(P2), _ptr(ji), _ptr(out), _ptr(codes)))
+        return out, codes[:, 0], codes[:, 1]
 
     def survive_mask(self, sic):
         sic = as_c(sic, np.float64, (self.Nj, self.Ni), "sic")

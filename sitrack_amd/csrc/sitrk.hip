@@ -755,7 +755,8 @@ SITRK_API int sitrk_eval_intersect(sitrk_t *h, int64_t n, const double *segs, in
     return SITRK_OK;
 }
 
-SITRK_API int sitrk_eval_crossing(sitrk_t *h, int64_t n, const double *P1, const double *P2, const int32_t *jiT, int32_t *jiT_new)
+SITRK_API int sitrk_eval_crossing(sitrk_t *h, int64_t n, const double *P1, const double *P2, const int32_t *jiT, int32_t *jiT_new,
+                                  int32_t *codes)
 {
     NEED(h, "null handle");
     NEED(h->geo, "sitrk_eval_crossing: call sitrk_set_grid first");
@@ -769,19 +770,21 @@ SITRK_API int sitrk_eval_crossing(sitrk_t *h, int64_t n, const double *P1, const
     HIPCHK(hipSetDevice(h->device));
     const size_t cells = (size_t)h->Nj * h->Ni;
     const size_t b_p = align256((size_t)n * sizeof(pt)), b_j = align256((size_t)n * 8), b_m = align256(cells);
-    int rc = ensure_scratch(h, 2 * b_p + 2 * b_j + b_m);
+    int rc = ensure_scratch(h, 2 * b_p + 3 * b_j + b_m);
     if (rc) return rc;
     char *s = (char *)h->scratch;
     pt *d1 = (pt *)s, *d2 = (pt *)(s + b_p);
-    int32_t *dj = (int32_t *)(s + 2 * b_p), *dn = (int32_t *)(s + 2 * b_p + b_j);
-    int8_t *zero = (int8_t *)(s + 2 * b_p + 2 * b_j);
+    int32_t *dj = (int32_t *)(s + 2 * b_p), *dn = (int32_t *)(s + 2 * b_p + b_j), *dc = (int32_t *)(s + 2 * b_p + 2 * b_j);
+    int8_t *zero = (int8_t *)(s + 2 * b_p + 3 * b_j);
     HIPCHK(hipMemcpyAsync(d1, P1, (size_t)n * sizeof(pt), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(d2, P2, (size_t)n * sizeof(pt), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(dj, jiT, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemsetAsync(zero, 0, cells, h->stream));
-    hipLaunchKernelGGL(eval_crossing_kernel, dim3(nblocks(n)), dim3(kBlock), 0, h->stream, n, h->Nj, h->Ni, h->geo, zero, d1, d2, dj, dn);
+    hipLaunchKernelGGL(eval_crossing_kernel, dim3(nblocks(n)), dim3(kBlock), 0, h->stream, n, h->Nj, h->Ni, h->geo, zero, d1, d2, dj, dn,
+                       codes ? dc : nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(jiT_new, dn, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+    if (codes) HIPCHK(hipMemcpyAsync(codes, dc, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return SITRK_OK;
 }

@@ -82,7 +82,7 @@ __device__ __forceinline__ pt load_f(const CellGeo *__restrict__ geo, int j, int
 // path costs one memory round trip instead of a chain of four.
 __device__ __forceinline__ int32_t resolve_crossing(pt P1, pt P2, pt bl, pt br, pt ur, pt ul, int jT, int iT, int Nj, int Ni,
                                                     const CellGeo *__restrict__ geo, const int8_t *__restrict__ kill,
-                                                    bool &killed)
+                                                    bool &killed, int *codes = nullptr)
 {
     // CrossedEdge (:189-200): first of bottom, right, upper, left hit; falls through to 4.
     // intersect2Seg(P1,P2,C,D) = (ccw(P1,C,D) != ccw(P2,C,D)) and (ccw(P1,P2,C) != ccw(P1,P2,D)); the second
@@ -121,6 +121,11 @@ __device__ __forceinline__ int32_t resolve_crossing(pt P1, pt P2, pt bl, pt br, 
     const int dj = hitA ? djA : (hitB ? djB : djS);
     const int di = hitA ? diA : (hitB ? diB : diS);
     killed = (hitA ? kA : (hitB ? kB : kS)) != 0;                           // Survive (:483-484)
+    if (codes) {                                                            // probes only: CrossedEdge / NewHostCell return values
+        const int cA = (kc == 1) ? 5 : (kc == 2) ? 6 : 8, cB = (kc == 1) ? 6 : (kc == 4) ? 5 : 7;
+        codes[0] = kc;
+        codes[1] = hitA ? cA : (hitB ? cB : kc);
+    }
     int32_t cn = pack_cell(jT + dj, iT + di);
     if (killed) cn |= SITRK_DEAD_BIT;
     return cn;
@@ -425,17 +430,22 @@ __global__ void eval_intersect_kernel(int64_t n, const pt *__restrict__ segs, in
 
 __global__ void eval_crossing_kernel(int64_t n, int Nj, int Ni, const CellGeo *__restrict__ geo, const int8_t *__restrict__ zero_mask,
                                      const pt *__restrict__ P1, const pt *__restrict__ P2, const int32_t *__restrict__ jiT,
-                                     int32_t *__restrict__ jiT_new)
+                                     int32_t *__restrict__ jiT_new, int32_t *__restrict__ codes_out)
 {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const int jT = jiT[2 * p], iT = jiT[2 * p + 1];
     const size_t k = (size_t)jT * Ni + iT;
     bool killed;
+    int codes[2];
     const int32_t cn = resolve_crossing(P1[p], P2[p], geo[k - Ni - 1].f, geo[k - Ni].f, geo[k].f, geo[k - 1].f, jT, iT, Nj, Ni, geo,
-                                        zero_mask, killed);
+                                        zero_mask, killed, codes);
     jiT_new[2 * p] = cell_j(cn);
     jiT_new[2 * p + 1] = cell_i(cn);
+    if (codes_out) {
+        codes_out[2 * p] = codes[0];                     // CrossedEdge: 1 bottom, 2 right, 3 upper, 4 left
+        codes_out[2 * p + 1] = codes[1];                 // NewHostCell: 1..4 or the diagonals 5..8
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -35,3 +35,17 @@ def nemoSeed(pmskT, platT, plonT, pIC, khss=1, fmsk_rstrct=[], platF=[], plonF=[
         keepF = msk_F == 1
         zLatLon = np.concatenate([zLatLon, np.stack([zlatF[keepF], zlonF[keepF]], axis=1).astype(np.float64)])
     return zLatLon
+
+
+def ReadFromSidfexDatFile(filepath='./sidfexloc.dat'):
+    """Text file `id lon lat` per line (reference sitrack/tracking.py:344-361)."""
+    import os
+    if not os.path.exists(filepath):
+        raise FileNotFoundError("'%s' file is missing." % filepath)
+    return np.atleast_2d(np.genfromtxt(filepath))
+
+
+def SidfexSeeding(filepath='./sidfexloc.dat'):
+    """Reference sitrack/tracking.py:331-341 -> (n,2) [lat,lon] and the buoy IDs (int)."""
+    dat = ReadFromSidfexDatFile(filepath)
+    return dat[:, [2, 1]], dat[:, 0].astype(int)

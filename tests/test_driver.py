@@ -262,3 +262,29 @@ def test_cli_two_ranks_equals_one(tmp_path, monkeypatch, two_d_time):
         b = ncio.LoadNCdata(str(d2 / f), krec=-1, lmask=True)
         for x, y in zip(a, b):
             assert np.array_equal(x, y)
+
+
+@pytest.mark.gpu
+def test_sidfex_seeding_reproduces_the_reference_fixture(tmp_path, monkeypatch, golden):
+    """The reference's committed seeding file tools/nc/sitrack_seeding_sidfex_19961215_00_HSS5.nc__KEEP was made by
+    `generate_sidfex_seeding.py -d 1996-12-15_00:00:00 --lsidfex 1 -k 0 -S 5` (tools/cmd.sh) from tools/sidfexloc.dat.
+    Same command through this build (projection on the GPU, own NetCDF writer) -> same name, same numbers."""
+    import importlib.util
+    g = golden("g7_projection.npz")
+    monkeypatch.chdir(tmp_path)
+    with open("sidfexloc.dat", "w") as f:
+        for i, (lon, lat) in zip(g["dat_id"], g["dat_lonlat"]):
+            f.write("%d %r %r\n" % (i, float(lon), float(lat)))
+    spec = importlib.util.spec_from_file_location("gis2", os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools",
+                                                                       "generate_idealized_seeding.py"))
+    gis = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gis)
+    fout = gis.main(["-d", "1996-12-15_00:00:00", "--lsidfex", "1", "-k", "0", "-S", "5"])
+    assert fout == "./nc/sitrack_seeding_sidfex_19961215_00_HSS5.nc"
+    with ncio._Reader(fout) as f:
+        assert np.array_equal(np.asarray(f.var("id_buoy")).astype(np.int64), g["id_buoy"])
+        assert np.array_equal(np.asarray(f.var("time")).astype(np.int64), g["time"])
+        for name, key in (("latitude", "latitude"), ("longitude", "longitude"), ("y_pos", "y_pos"), ("x_pos", "x_pos")):
+            got = np.asarray(f.var(name)).astype(np.float32)[0]
+            assert np.array_equal(got, g[key]), name          # float32, bit for bit
+        assert f.attr("time", "units") == ncio.tunits_default and f.attr("y_pos", "units") == "km"

@@ -41,8 +41,10 @@ def test_g3_crossing_chain_on_device(golden, ctx):
     g = golden("g3_crossing.npz")
     Nj, Ni = g["Yf"].shape
     ctx.set_grid(g["Yf"], g["Xf"], g["Yf"], g["Xf"], g["Yf"], g["Xf"], np.ones((Nj, Ni), dtype=np.int8))
-    got = ctx.eval_crossing(g["P1"], g["P2"], g["jiT"])
-    assert np.array_equal(got, g["jiT_out"])
+    got, icross, inhc = ctx.eval_crossing(g["P1"], g["P2"], g["jiT"])
+    assert np.array_equal(icross, g["icross"])                   # CrossedEdge, incl. the fall-through to 4
+    assert np.array_equal(inhc, g["inhc"])                       # NewHostCell, all 8 codes
+    assert np.array_equal(got, g["jiT_out"])                     # UpdtInd4NewCell
     assert set(np.unique(g["inhc"])) == set(range(1, 9))
     with pytest.raises(IndexError):
         ctx.eval_crossing(g["P1"][:1], g["P2"][:1], np.array([[0, 3]]))

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Seeding file on the model grid -- the flags of the reference tool of the same name
-(tools/generate_idealized_seeding.py:40-83: -d -m -i -v -k -S -f -N) minus the coarsening path (-C needs
-`gudhi`/`mojito`).  Writes ./nc/sitrack_seeding_<nemoTsi3|nemoTmm>_<YYYYMMDD_hh>[_HSS<S>].nc with the schema of
-reference ncio.py:131-197."""
+"""Seeding file on the model grid -- the flags of the reference tools generate_idealized_seeding.py /
+generate_sidfex_seeding.py (-d -m -i -v -k -S -f -N, --lsidfex) minus the coarsening path (-C needs
+`gudhi`/`mojito`).  Writes ./nc/sitrack_seeding_<nemoTsi3|nemoTmm|sidfex>_<YYYYMMDD_hh>[_HSS<S>].nc with the schema
+of reference ncio.py:131-197.  `--lsidfex 1` seeds from a text file `id lon lat` (reference tools/sidfexloc.dat)."""
 import argparse
 import os
 import sys
@@ -14,13 +14,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import sitrack_amd as sit                      # noqa: E402
 from sitrack_amd import driver, ncio           # noqa: E402
-from sitrack_amd.seeding import nemoSeed       # noqa: E402
+from sitrack_amd.seeding import nemoSeed, SidfexSeeding       # noqa: E402
 
 
 def main(argv=None):
     ap = argparse.ArgumentParser(description='SITRACK idealised seeding (MI355X build)')
     ap.add_argument('-d', '--dat0', required=True, help='initial date in the form <YYYY-MM-DD_hh:mm:ss>')
-    ap.add_argument('-m', '--fmmm', required=True, help='model `mesh_mask` file of NEMO config used in SI3 run')
+    ap.add_argument('-m', '--fmmm', default=None, help='model `mesh_mask` file of NEMO config used in SI3 run')
+    ap.add_argument('--lsidfex', type=int, default=0, help='Switch to 1 for SIDFEX seeding.')
+    ap.add_argument('--sidfex-file', default='./sidfexloc.dat', help='text file `id lon lat` (extra; the reference hard-codes ./sidfexloc.dat)')
     ap.add_argument('-i', '--fsi3', default=None, help='output file of SI3 containing sea-ice concentration')
     ap.add_argument('-v', '--nsic', default='siconc', help='name of sea-ice concentration in SI3 file')
     ap.add_argument('-k', '--krec', type=int, default=0, help='use sea-ice concentration at this record')
@@ -34,8 +36,13 @@ def main(argv=None):
         raise SystemExit('-C/--crsn needs the gudhi-based SubSampCloud of `mojito`: out of scope of this build')
     if a.ihss < 1 or a.ihss > 20:
         raise SystemExit('ERROR: chosen horizontal subsampling makes no sense iHSS=%d' % a.ihss)
-    seeding_type = 'nemoTsi3' if a.fsi3 else 'nemoTmm'
+    seeding_type = 'sidfex' if a.lsidfex == 1 else ('nemoTsi3' if a.fsi3 else 'nemoTmm')
     ctx = sit.Context(a.device)
+    if seeding_type == 'sidfex':
+        XseedGC, zIDs = SidfexSeeding(a.sidfex_file)
+        return write_seeding(ctx, a, seeding_type, XseedGC, zIDs)
+    if not a.fmmm:
+        raise SystemExit('ERROR: you have to specify a MeshMask file with `-m`')
     imaskt, xlatT, xlonT, xYt, xXt, xYf, xXf, xResKM = ncio.GetModelGrid(a.fmmm, ctx)
     if a.fsi3:
         rec = ncio.ModelRecords(a.fsi3)
@@ -52,8 +59,12 @@ def main(argv=None):
         if np.shape(FSmask) != np.shape(imaskt):
             raise SystemExit('ERROR: `shape(FSmask) != shape(imaskt)`')
     XseedGC = nemoSeed(imaskt, xlatT, xlonT, xIC, khss=a.ihss, fmsk_rstrct=FSmask)
+    zIDs = np.arange(1, XseedGC.shape[0] + 1, dtype=int)
+    return write_seeding(ctx, a, seeding_type, XseedGC, zIDs)
+
+
+def write_seeding(ctx, a, seeding_type, XseedGC, zIDs):
     nP = XseedGC.shape[0]
-    zIDs = np.arange(1, nP + 1, dtype=int)
     t0 = driver.clock2epoch(a.dat0)
     XseedYX = sit.Geo2CartNPSkm1D(XseedGC, ctx=ctx)
     cdate = datetime.fromtimestamp(t0, timezone.utc).strftime("%Y%m%d_%H")
