@@ -1,0 +1,52 @@
+/* Plain-C consumer of include/sitrk.h: proves the boundary is a C ABI (no C++/Python types in it).
+ * Built and run by tests/test_abi.py with gcc.  Without a GPU it must fail cleanly at sitrk_create;
+ * with one it pushes a tiny grid, one record and three buoys through a step and reads them back. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "sitrk.h"
+
+int main(void)
+{
+    sitrk_t *h = NULL;
+    printf("version %d\n", sitrk_version());
+    int rc = sitrk_create(&h, 0);
+    if (rc != SITRK_OK) {
+        printf("create failed (%d): %s\n", rc, sitrk_last_error(NULL));
+        return rc == SITRK_EHIP ? 3 : 1;               /* 3 = no device: the expected outcome on a CPU box */
+    }
+    enum { N = 16 };
+    static double Yf[N * N], Xf[N * N], Yu[N * N], Xu[N * N], Yv[N * N], Xv[N * N];
+    static int8_t tmask[N * N];
+    static float u[N * N], v[N * N], sic[N * N];
+    for (int j = 0; j < N; j++)
+        for (int i = 0; i < N; i++) {
+            int k = j * N + i;
+            Yf[k] = 4.0 * (j + 0.5); Xf[k] = 4.0 * (i + 0.5);
+            Yu[k] = 4.0 * j;         Xu[k] = 4.0 * (i + 0.5);
+            Yv[k] = 4.0 * (j + 0.5); Xv[k] = 4.0 * i;
+            tmask[k] = 1; u[k] = 0.5f; v[k] = -0.25f; sic[k] = 1.0f;
+        }
+#define CHK(call) do { rc = (call); if (rc) { printf("%s -> %d: %s\n", #call, rc, sitrk_last_error(h)); return 1; } } while (0)
+    CHK(sitrk_set_grid(h, N, N, Yf, Xf, Yu, Xu, Yv, Xv, tmask));
+    CHK(sitrk_set_params(h, 3600.0, 1, 0.1));
+    CHK(sitrk_alloc_records(h, 1, SITRK_F32));
+    CHK(sitrk_push_record(h, 0, u, v, sic));
+    double yx[6] = {20.0, 20.0, 30.5, 33.0, 41.0, 27.9};     /* cells (5,5) (8,8) (10,7) */
+    int32_t ji[6] = {5, 5, 8, 8, 10, 7};
+    CHK(sitrk_set_buoys(h, 3, yx, ji, NULL, NULL));
+    CHK(sitrk_step(h, 0, 0));
+    double out[6]; int32_t jo[6]; int8_t alive[3]; int32_t kr[3];
+    CHK(sitrk_fetch(h, out, jo, alive, kr));
+    for (int p = 0; p < 3; p++) {
+        /* dx = 0.5*3600/1000 = 1.8 km, dy = -0.9 km, exactly as the reference computes them */
+        double ey = yx[2 * p] + (-0.25 * 3600.0) / 1000.0, ex = yx[2 * p + 1] + (0.5 * 3600.0) / 1000.0;
+        printf("buoy %d: (%.17g, %.17g) cell (%d,%d) alive %d\n", p, out[2 * p], out[2 * p + 1], jo[2 * p], jo[2 * p + 1], alive[p]);
+        if (out[2 * p] != ey || out[2 * p + 1] != ex) { printf("unexpected position\n"); return 1; }
+    }
+    int64_t nalive = -1;
+    CHK(sitrk_count_alive(h, &nalive));
+    CHK(sitrk_destroy(h));
+    printf("ok (%lld alive)\n", (long long)nalive);
+    return 0;
+}

@@ -35,6 +35,33 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert L.sitrk_version() == 100
 
 
+def _build_c_consumer(tmp_path):
+    exe = str(tmp_path / "abi_smoke")
+    so_dir = os.path.join(ROOT, "sitrack_amd")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-o", exe, "-L", so_dir, "-l:libsitrk.so",
+                    "-Wl,-rpath," + so_dir], check=True)
+    return exe
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/sitrk.h compiles as C11 and a C program links against libsitrk.so; without a GPU it fails cleanly."""
+    _lib.build()
+    exe = _build_c_consumer(tmp_path)
+    import torch
+    r = subprocess.run([exe], capture_output=True, text=True)
+    if torch.cuda.is_available():
+        assert r.returncode == 0, r.stdout + r.stderr
+    else:
+        assert r.returncode == 3 and "no HIP device" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_c_consumer_steps_three_buoys(tmp_path):
+    r = subprocess.run([_build_c_consumer(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0 and "ok (3 alive)" in r.stdout, r.stdout + r.stderr
+
+
 def test_no_cpu_fallback_without_a_device():
     import torch
     if torch.cuda.is_available():
