@@ -97,6 +97,16 @@ void *sitrk_record_ptr(sitrk_t *h, int slot);   /* device address of a slot's sl
  * by themselves; a slot handed out by sitrk_record_ptr and never committed is committed by the next step. */
 int   sitrk_commit_record(sitrk_t *h, int slot);
 
+/* Row-band ingest.  A step of a buoy hosted by row jT reads u,v in rows jT-1..jT and Survive bytes in rows jT-1..jT+1,
+ * which derive from siconc rows jT-2..jT+2; and a host cell moves by at most one row per record (UpdtInd4NewCell,
+ * sitrack/tracking.py:257-300).  So with [jmin,jmax] = sitrk_buoy_rows() (rows of the buoys still alive; jmin > jmax
+ * when none) the next step can only touch rows [jmin-2, jmax+3) of a record, and only those need to be uploaded:
+ * sitrk_push_record_rows copies rows [j0,j1) of the (Nj,Ni) fields (host arrays holding just those rows) into the slot
+ * and derives the Survive bytes they determine (rows j0+1..j1-2 and the domain rim); other rows keep what they held.
+ * Each rank of a multi-GPU run can thus ingest only the band of its own buoys: no collective at all. */
+int sitrk_buoy_rows(sitrk_t *h, int32_t *jmin, int32_t *jmax);
+int sitrk_push_record_rows(sitrk_t *h, int slot, int j0, int j1, const void *u_rows, const void *v_rows, const void *sic_rows);
+
 /* ---- buoys ---------------------------------------------------------------
  * State of si3_part_tracker.py:324-330 reduced to what the loop reads:
  * yx = xPosC[jt] (nP,2) km; jiT = vJIt (nP,2); rec_first/rec_last =

@@ -36,6 +36,8 @@ _SIGNATURES = {
     "sitrk_alloc_records": (_int, [_vp, _int, _int]),
     "sitrk_push_record": (_int, [_vp, _int, _vp, _vp, _vp]),
     "sitrk_push_record_dev": (_int, [_vp, _int, _vp]),
+    "sitrk_buoy_rows": (_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "sitrk_push_record_rows": (_int, [_vp, _int, _int, _int, _vp, _vp, _vp]),
     "sitrk_record_ptr": (_vp, [_vp, _int]),
     "sitrk_commit_record": (_int, [_vp, _int]),
     "sitrk_set_buoys": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
@@ -186,6 +188,28 @@ class Context:
         sic = as_c(sic, self.field_dtype, shp, "sic")
         self._chk(self._L.sitrk_push_record(self._h, int(slot), _ptr(u), _ptr(v), _ptr(sic)))
         self.sync()             # u,v,sic may be temporaries
+
+    def buoy_rows(self):
+        """(jmin, jmax) of the host rows of the buoys still alive; jmin > jmax when there is none."""
+        a, b = C.c_int32(0), C.c_int32(0)
+        self._chk(self._L.sitrk_buoy_rows(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def band(self, age=0):
+        """Rows [j0,j1) of a record the next step(s) can touch: [jmin-2-age, jmax+3+age) clipped to the grid, where `age`
+        = number of records stepped since buoy_rows() was evaluated (a host cell moves at most one row per record)."""
+        jmin, jmax = self.buoy_rows()
+        if jmin > jmax:
+            return 0, 0
+        return max(0, jmin - 2 - age), min(self.Nj, jmax + 3 + age)
+
+    def push_record_rows(self, slot, j0, j1, u_rows, v_rows, sic_rows):
+        shp = (j1 - j0, self.Ni)
+        u = as_c(u_rows, self.field_dtype, shp, "u rows")
+        v = as_c(v_rows, self.field_dtype, shp, "v rows")
+        s = as_c(sic_rows, self.field_dtype, shp, "sic rows")
+        self._chk(self._L.sitrk_push_record_rows(self._h, int(slot), int(j0), int(j1), _ptr(u), _ptr(v), _ptr(s)))
+        self.sync()
 
     def push_record_dev(self, slot, dev_ptr):
         self._chk(self._L.sitrk_push_record_dev(self._h, int(slot), _vp(dev_ptr)))

@@ -287,6 +287,54 @@ SITRK_API int sitrk_push_record(sitrk_t *h, int slot, const void *u, const void 
     return derive_mask(h, slot);
 }
 
+SITRK_API int sitrk_buoy_rows(sitrk_t *h, int32_t *jmin, int32_t *jmax)
+{
+    NEED(h, "null handle");
+    NEED(jmin && jmax, "sitrk_buoy_rows: null output");
+    *jmin = 1; *jmax = 0;
+    if (h->nP == 0) return SITRK_OK;
+    NEED(h->st[0].pos, "sitrk_buoy_rows: call sitrk_set_buoys first");
+    HIPCHK(hipSetDevice(h->device));
+    int init[2] = {0x7fffffff, -1}, res[2];
+    int *d = (int *)h->counter;                                     // 8 bytes
+    HIPCHK(hipMemcpyAsync(d, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(buoy_rows_kernel, dim3(std::min(nblocks(h->nP), 2048u)), dim3(kBlock), 0, h->stream, h->nP, h->st[h->cur].cell, d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(res, d, sizeof(res), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (res[1] >= 0) { *jmin = res[0]; *jmax = res[1]; }
+    return SITRK_OK;
+}
+
+SITRK_API int sitrk_push_record_rows(sitrk_t *h, int slot, int j0, int j1, const void *u_rows, const void *v_rows, const void *sic_rows)
+{
+    NEED(h, "null handle");
+    NEED(h->slabs, "sitrk_push_record_rows: call sitrk_alloc_records first");
+    NEED(slot >= 0 && slot < h->nslots, "sitrk_push_record_rows: slot out of range");
+    NEED(j0 >= 0 && j1 <= h->Nj && j0 <= j1, "sitrk_push_record_rows: rows out of range");
+    if (j0 == j1) return SITRK_OK;
+    NEED(u_rows && v_rows && sic_rows, "sitrk_push_record_rows: null field");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t n = (size_t)h->Nj * h->Ni, es = elem_size(h->dtype);
+    const size_t off = (size_t)j0 * h->Ni * es, nb = (size_t)(j1 - j0) * h->Ni * es;
+    char *d = slab_of(h, slot);
+    HIPCHK(hipMemcpyAsync(d + off, u_rows, nb, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d + n * es + off, v_rows, nb, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d + 2 * n * es + off, sic_rows, nb, hipMemcpyHostToDevice, h->stream));
+    // the Survive bytes these rows determine
+    int8_t *kill = h->kill + (size_t)slot * n;
+    const int64_t cells = (int64_t)(j1 - j0) * h->Ni;
+    if (h->dtype == SITRK_F64)
+        hipLaunchKernelGGL((survive_mask_rows_kernel<double>), dim3(nblocks(cells)), dim3(kBlock), 0, h->stream, h->Nj, h->Ni, j0, j1, j0, j1,
+                           h->tmask, (const double *)(d + 2 * n * es), h->rmin_conc, kill);
+    else
+        hipLaunchKernelGGL((survive_mask_rows_kernel<float>), dim3(nblocks(cells)), dim3(kBlock), 0, h->stream, h->Nj, h->Ni, j0, j1, j0, j1,
+                           h->tmask, (const float *)(d + 2 * n * es), h->rmin_conc, kill);
+    HIPCHK(hipGetLastError());
+    h->slot_dirty[slot] = 0;            // the caller vouches for the rows a step can touch (sitrk_buoy_rows)
+    return SITRK_OK;
+}
+
 SITRK_API int sitrk_push_record_dev(sitrk_t *h, int slot, const void *slab_dev)
 {
     NEED(h, "null handle");

@@ -69,6 +69,39 @@ __global__ void survive_mask_kernel(int Nj, int Ni, const int8_t *__restrict__ t
     kill[k] = survive_kill<FT>(j, i, Nj, Ni, tmask, sic, rmin_conc) ? 1 : 0;
 }
 
+// Same for the rows [j_lo, j_hi) only, of which the siconc rows [v_lo, v_hi) are valid: a row is derived when its
+// 3-row stencil is valid or when it belongs to the domain rim (killed whatever the ice is).  Row-band ingest.
+template <typename FT>
+__global__ void survive_mask_rows_kernel(int Nj, int Ni, int j_lo, int j_hi, int v_lo, int v_hi, const int8_t *__restrict__ tmask,
+                                         const FT *__restrict__ sic, double rmin_conc, int8_t *__restrict__ kill)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)(j_hi - j_lo) * Ni) return;
+    const int j = j_lo + (int)(t / (size_t)Ni), i = (int)(t % (size_t)Ni);
+    const bool rim = (j <= 1 || j >= Nj - 2);
+    if (!rim && (j - 1 < v_lo || j + 1 >= v_hi)) return;      // stencil not inside the uploaded rows: leave the byte alone
+    kill[(size_t)j * Ni + i] = survive_kill<FT>(j, i, Nj, Ni, tmask, sic, rmin_conc) ? 1 : 0;
+}
+
+// rows of the host cells of the buoys that are still alive: out[0] = min jT, out[1] = max jT
+__global__ __launch_bounds__(kBlock) void buoy_rows_kernel(int64_t n, const int32_t *__restrict__ cell, int *out)
+{
+    __shared__ int smin[kBlock / 64], smax[kBlock / 64];
+    int lo = 0x7fffffff, hi = -1;
+    for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < n; s += (int64_t)gridDim.x * kBlock) {
+        const int32_t c = cell[s];
+        if (c >= 0) { const int j = cell_j(c); lo = min(lo, j); hi = max(hi, j); }
+    }
+    for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_down(lo, off)); hi = max(hi, __shfl_down(hi, off)); }
+    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = lo; smax[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; w++) { lo = min(lo, smin[w]); hi = max(hi, smax[w]); }
+        atomicMin(&out[0], lo);
+        atomicMax(&out[1], hi);
+    }
+}
+
 __device__ __forceinline__ pt load_f(const CellGeo *__restrict__ geo, int j, int i, int Nj, int Ni)
 {
     return geo[(size_t)pywrap(j, Nj) * Ni + pywrap(i, Ni)].f;

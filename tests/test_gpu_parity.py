@@ -274,6 +274,47 @@ def test_everything_dies_and_stays_dead():
     trk.close()
 
 
+@pytest.mark.parametrize("fdt", [np.float32, np.float64])
+def test_row_band_ingest_equals_full_ingest(fdt):
+    """Only rows [jmin-2, jmax+3) of a record are uploaded; the rest of the slot is poisoned (NaN velocities, zero ice
+    => Survive kills).  Trajectories must equal those of full uploads: nothing outside the band is ever read."""
+    Nj, Ni = 200, 96
+    grid = syn.make_grid(Nj, Ni, dkm=4.0, warp=1.0)
+    K, Nt = 6, 45
+    u, v, sic = syn.make_fields(grid, K=K, seed=21, umax=1.1, drift=0.7, ripple=0.1, dtype=fdt)   # fast: ~1 cell per record
+    tmask = grid["tmask"].copy(); tmask[88:92, 30:50] = 0
+    sic[:, 60:70, 10:30] = 0.03
+    _, yx = syn.make_buoys(grid, 15000, seed=12, frac=0.9)
+    yx = yx[np.abs(yx[:, 0]) < 120.]                         # a band of rows in the middle of the mesh
+    res = {}
+    for mode in ("full", "band"):
+        trk = make_tracker(grid, tmask, 1, field_dtype=fdt)
+        found, ji, _ = sit.FindContainingCell(yx, syn.nearest_t_plane(grid, yx), ctx=trk.ctx)
+        trk.set_buoys(yx[found], ji[found])
+        poison = (np.full((Nj, Ni), np.nan, dtype=fdt), np.full((Nj, Ni), np.nan, dtype=fdt), np.zeros((Nj, Ni), dtype=fdt))
+        bands = []
+        for s in range(Nt):
+            k = s % K
+            if mode == "full":
+                trk.ctx.push_record(0, u[k], v[k], sic[k])
+            else:
+                trk.ctx.push_record(0, *poison)
+                j0, j1 = trk.ctx.band()
+                bands.append((j0, j1))
+                trk.ctx.push_record_rows(0, j0, j1, u[k][j0:j1], v[k][j0:j1], sic[k][j0:j1])
+            trk.step(s, 0)
+        res[mode] = trk.state()
+        if mode == "band":
+            assert max(b[1] - b[0] for b in bands) < 0.8 * Nj and bands[0] != bands[-1]      # a real band, and it moved
+            jmin, jmax = trk.ctx.buoy_rows()
+            alive = res[mode]["iAlive"] == 1
+            assert (jmin, jmax) == (res[mode]["vJIt"][alive, 0].min(), res[mode]["vJIt"][alive, 0].max())
+        trk.close()
+    for key in ("yx", "vJIt", "iAlive", "kill_rec"):
+        assert np.array_equal(res["band"][key], res["full"][key]), key
+    assert not np.isnan(res["band"]["yx"]).any() and 0 < res["band"]["iAlive"].sum() < len(res["band"]["iAlive"])
+
+
 def test_run_many_steps_equals_stepping(ctx):
     grid = syn.make_grid(96, 96, dkm=4.0, warp=1.0)
     u, v, sic = syn.make_fields(grid, K=3, seed=3, umax=0.6, drift=0.2)
