@@ -6,7 +6,8 @@ Same flags and defaults (reference si3_part_tracker.py:42-73), same module const
 2-D-time mode (:264-318), same NetCDF outputs (:515-571) -- the per-buoy loop (:378-490) and the
 per-record inverse projection (:493) run on the GPU.  Differences, all opt-in or forced:
 extra flags `--device`, `--uv-strategy`; under `torchrun` (WORLD_SIZE > 1) the buoys are range-partitioned over the
-ranks, rank 0 reads each record and broadcasts its slab (RCCL), rank 0 writes the files; errors raise instead of
+ranks by latitude band and every rank reads only the rows of each record its own buoys can touch (row-band ingest, no
+collective; `--full-records`: rank 0 reads, RCCL broadcast), rank 0 writes the files; errors raise instead of
 `print; exit(0)`; maps need the
 optional `mojito` package and are skipped without it; the full (Nt+1,nP,2) series is only kept in
 host memory when it is written (`-F`) instead of always (the reference's 320 GB at 1e7 buoys x 1000 records).
@@ -54,6 +55,9 @@ def parse_args(argv=None):
     ap.add_argument('-p', '--plot', type=int, default=0, help='how often, in terms of model records, we plot the positions on a map')
     ap.add_argument('--device', type=int, default=0, help='GPU to use (extra)')
     ap.add_argument('--uv-strategy', type=int, default=1, choices=(0, 1), help='iUVstrategy of the reference, default 1 (extra)')
+    ap.add_argument('--full-records', action='store_true',
+                    help='read and upload whole records (under torchrun: rank 0 reads, RCCL broadcast) instead of only the rows '
+                         'each rank\'s buoys can touch (extra; same results)')
     return ap.parse_args(argv)
 
 
@@ -184,12 +188,23 @@ def main(argv=None):
         z1stModelRec, zLstModelRec = record_windows(zTpos, ztime_model, kstrt, kstop, iTmA, iTmB, nP)
     k0 = z1stModelRec - kstrt
 
-    # ---- device state: this rank's contiguous range [lo,hi) of the buoys
+    # ---- device state.  Under torchrun every rank owns a contiguous range of the buoys ordered by host row, i.e. a
+    #      latitude band: with row-band ingest each rank then reads only its own rows of every record, no collective.
+    order = np.arange(nP) if comm.world == 1 else np.argsort(vJIt[:, 0], kind='stable')
     lo, hi = comm.range(nP)
+    mine = order[lo:hi]
+
+    def to_caller_order(rows):            # rows gathered in rank order -> the caller's buoy order
+        if rows is None or comm.world == 1:
+            return rows
+        out = np.empty_like(rows)
+        out[order] = rows
+        return out
+
     (u0,) = records.fields(kstrt, ('u_ice',))
     fdt = np.float64 if np.asarray(u0).dtype == np.float64 else np.float32
     trk = IceTracker(xYf, xXf, xYu, xXu, xYv, xXv, imaskt, rdt=rdt, iUVstrategy=iUVstrategy, nslots=1, field_dtype=fdt, ctx=ctx)
-    trk.set_buoys(xPosC0[lo:hi], vJIt[lo:hi], z1stModelRec[lo:hi] if lUse2DTime else None, zLstModelRec[lo:hi] if lUse2DTime else None)
+    trk.set_buoys(xPosC0[mine], vJIt[mine], z1stModelRec[mine] if lUse2DTime else None, zLstModelRec[mine] if lUse2DTime else None)
 
     # ---- host arrays (rank 0): the full series only when it is written
     lFull = (not lUse2DTime) or a.plot > 0
@@ -222,16 +237,18 @@ def main(argv=None):
         vTime[jt] = itime
         nalive = comm.sum_int(trk.alive_count())
         say(' *** record #%d/%d  date = %s   buoys alive = %d' % (jrec + 1, Nt0, epoch2clock(itime), nalive))
-        fields = records.fields(jrec) if comm.root else None          # rank 0 ingests the record (:372-374) ...
-        if comm.world == 1:
-            trk.load_record(0, *fields)
+        if not a.full_records:
+            j0, j1 = trk.band()                                         # rows this rank's buoys can touch in this record
+            trk.load_record_rows(0, j0, j1, *records.fields_rows(jrec, j0, j1))
+        elif comm.world == 1:
+            trk.load_record(0, *records.fields(jrec))                   # the whole record (:372-374)
         else:
-            comm.deliver_record(ctx, 0, fields)                         # ... and broadcasts its slab
+            comm.deliver_record(ctx, 0, records.fields(jrec) if comm.root else None)   # rank 0 reads, RCCL broadcast
         trk.step(jrec, 0)
         need = lFull or (lUse2DTime and jrec in ends)
         if need:
             pos_l, msk_l = trk.record(jrec)
-            pos, msk = comm.gather_rows(pos_l, nP), comm.gather_rows(msk_l, nP)
+            pos, msk = to_caller_order(comm.gather_rows(pos_l, nP)), to_caller_order(comm.gather_rows(msk_l, nP))
         if need and comm.root:
             stepped = msk == 1
             if lFull:
@@ -247,7 +264,7 @@ def main(argv=None):
     records.close()
     vTime[Nt] = vTime[Nt - 1] + int(rdt)
     state = trk.state()
-    vJIt_end, alive_end = comm.gather_rows(state["vJIt"], nP), comm.gather_rows(state["iAlive"], nP)
+    vJIt_end, alive_end = to_caller_order(comm.gather_rows(state["vJIt"], nP)), to_caller_order(comm.gather_rows(state["iAlive"], nP))
     trk.close()
     if not comm.root:
         comm.close()

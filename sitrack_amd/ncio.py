@@ -223,6 +223,10 @@ class ModelRecords:
     def fields(self, jrec, names=('u_ice', 'v_ice', 'siconc')):
         return tuple(self.f.var(n, jrec) for n in names)
 
+    def fields_rows(self, jrec, j0, j1, names=('u_ice', 'v_ice', 'siconc')):
+        """rows [j0,j1) only (row-band ingest: a rank reads just the rows its buoys can touch)"""
+        return tuple(self.f.var(n, (jrec, slice(j0, j1))) for n in names)
+
     def close(self):
         self.f.close()
 

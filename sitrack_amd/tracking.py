@@ -141,14 +141,26 @@ class IceTracker:
     def set_buoys(self, xPosC0, vJIt, z1stModelRec=None, zLstModelRec=None, sort=True):
         self.ctx.set_buoys(xPosC0, vJIt, z1stModelRec, zLstModelRec, sort=sort)
 
-    def load_record(self, slot, xUu, xVv, xIC):
-        """Fields must be exactly representable in the record dtype (NEMO output is f4)."""
+    def _check_exact(self, xUu, xVv, xIC):
         dt = self.ctx.field_dtype
         for nm, a in (("u_ice", xUu), ("v_ice", xVv), ("siconc", xIC)):
             a = np.asarray(a)
             if a.dtype != dt and not np.array_equal(a.astype(dt).astype(a.dtype), a, equal_nan=True):
                 raise ValueError("%s is not exactly representable as %s; allocate float64 records" % (nm, dt))
+
+    def load_record(self, slot, xUu, xVv, xIC):
+        """Fields must be exactly representable in the record dtype (NEMO output is f4)."""
+        self._check_exact(xUu, xVv, xIC)
         self.ctx.push_record(slot, xUu, xVv, xIC)
+
+    def band(self, age=0):
+        """Rows [j0,j1) of the next record(s) that this tracker's buoys can touch (see sitrk_buoy_rows)."""
+        return self.ctx.band(age)
+
+    def load_record_rows(self, slot, j0, j1, xUu_rows, xVv_rows, xIC_rows):
+        """Row-band ingest: only rows [j0,j1) of the record, as returned by band()."""
+        self._check_exact(xUu_rows, xVv_rows, xIC_rows)
+        self.ctx.push_record_rows(slot, j0, j1, xUu_rows, xVv_rows, xIC_rows)
 
     def step(self, jrec, slot=0):
         self.ctx.step(slot, jrec)

@@ -232,8 +232,8 @@ def _dist_worker(rank, world, port, tmp, argv, q):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("two_d_time", [False, True])
-def test_cli_two_ranks_equals_one(tmp_path, monkeypatch, two_d_time):
+@pytest.mark.parametrize("two_d_time,extra", [(False, []), (True, []), (False, ["--full-records"])])
+def test_cli_two_ranks_equals_one(tmp_path, monkeypatch, two_d_time, extra):
     """N>1 driver path rehearsed with 2 ranks on the one GPU of the box (gloo moves the record slabs; RCCL refuses
     two ranks per device): buoy-range partition, per-range SeedInit, record delivery, gathers -> same files."""
     import socket
@@ -243,7 +243,8 @@ def test_cli_two_ranks_equals_one(tmp_path, monkeypatch, two_d_time):
     c = make_case(str(tmp_path), two_d_time=two_d_time)
     argv = ["-i", c["si3"], "-m", c["mm"], "-s", c["seed"], "-N", "TEST4"] + ([] if two_d_time else ["-F"])
     monkeypatch.chdir(d1)
-    one = drv.main(argv)
+    one = drv.main(argv + ["--full-records"])          # the single-rank run ingests whole records
+    argv = argv + extra                                # the 2-rank run: row bands by default
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
