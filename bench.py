@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--check", action="store_true", help="verify a subsample against the oracle after the run")
     ap.add_argument("--fuse", type=int, default=8,
                     help="resident records advanced per launch by sitrk_run (loop interchange; 1 = one launch per record)")
+    ap.add_argument("--e2e-full", action="store_true", help="e2e regime: upload whole records instead of the row band the buoys can touch")
     ap.add_argument("--regime", default="resident", choices=["resident", "e2e"],
                     help="resident: records live in HBM (the metric). e2e: every step's record is uploaded from pinned host "
                          "memory on rank 0 (+ RCCL broadcast), double-buffered against the stepping; reported for context only")
@@ -208,23 +209,41 @@ def main():
         ready = [torch.cuda.Event(), torch.cuda.Event()]
         free = [torch.cuda.Event(), torch.cuda.Event()]
 
+        n_cells = Nj * Ni
+        band = {"eval": -10**9, "jmin": 0, "jmax": Nj - 1, "rows": [None, None], "bytes": 0}
+
         def deliver(sidx):
             b = sidx % 2
+            if a.e2e_full or dist is not None:
+                j0, j1 = 0, Nj
+            else:
+                # row-band ingest: rows the buoys can touch at record sidx, from the host rows sampled `age` records ago
+                age = sidx - band["eval"]
+                j0, j1 = max(0, band["jmin"] - 2 - age), min(Nj, band["jmax"] + 3 + age)
+            band["rows"][b] = (j0, j1)
+            band["bytes"] += 3 * (j1 - j0) * Ni * 4
             with torch.cuda.stream(copy):
                 copy.wait_event(free[b])
                 if rank == 0:
-                    slots[b].copy_(pinned[sidx % K], non_blocking=True)
+                    src = pinned[sidx % K]
+                    for f in range(3):
+                        lo_, hi_ = f * n_cells + j0 * Ni, f * n_cells + j1 * Ni
+                        slots[b][lo_:hi_].copy_(src[lo_:hi_], non_blocking=True)
                 if dist is not None:
                     dist.broadcast(slots[b], src=0)
                 ready[b].record(copy)
 
         def run_e2e(s0, n):
-            deliver(s0)
             for sidx in range(s0, s0 + n):
+                if not (a.e2e_full or dist is not None) and (sidx - band["eval"]) >= 32:
+                    band["jmin"], band["jmax"] = ctx.buoy_rows()          # syncs the compute stream every 32 records
+                    band["eval"] = sidx
+                if sidx == s0:
+                    deliver(sidx)
                 if sidx + 1 < s0 + n:
                     deliver(sidx + 1)
                 comp.wait_event(ready[sidx % 2])
-                ctx.commit_record(sidx % 2)          # the slab was rewritten in place: refresh its Survive mask
+                ctx.commit_record_rows(sidx % 2, *band["rows"][sidx % 2])   # refresh the Survive bytes of the rows just written
                 ctx.step(sidx % 2, sidx)
                 free[sidx % 2].record(comp)
 
@@ -239,6 +258,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         ctx.set_stream(None)
+        e2e_bytes_per_step = band["bytes"] / float(a.warmup + a.steps)
     if dist is not None:
         t = torch.tensor([dt, ev_ms], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -303,6 +323,7 @@ def main():
                        "records_resident": K, "record_dtype": "f32", "uv_strategy": a.uv_strategy,
                        "sorted": not a.no_sort, "resort_every": 0 if a.no_sort else resort, "regime": a.regime,
                        "records_per_launch": fuse,
+                       "e2e_upload_bytes_per_step": (e2e_bytes_per_step if a.regime == "e2e" else None),
                        "partition": "buoy-range x%d" % world, "alive_after": nalive},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_fused if fuse > 1 else traffic,

@@ -106,6 +106,8 @@ int   sitrk_commit_record(sitrk_t *h, int slot);
  * Each rank of a multi-GPU run can thus ingest only the band of its own buoys: no collective at all. */
 int sitrk_buoy_rows(sitrk_t *h, int32_t *jmin, int32_t *jmax);
 int sitrk_push_record_rows(sitrk_t *h, int slot, int j0, int j1, const void *u_rows, const void *v_rows, const void *sic_rows);
+/* same derivation for rows [j0,j1) that the caller wrote in place through sitrk_record_ptr (device-side copies) */
+int sitrk_commit_record_rows(sitrk_t *h, int slot, int j0, int j1);
 
 /* ---- buoys ---------------------------------------------------------------
  * State of si3_part_tracker.py:324-330 reduced to what the loop reads:

@@ -38,6 +38,7 @@ _SIGNATURES = {
     "sitrk_push_record_dev": (_int, [_vp, _int, _vp]),
     "sitrk_buoy_rows": (_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sitrk_push_record_rows": (_int, [_vp, _int, _int, _int, _vp, _vp, _vp]),
+    "sitrk_commit_record_rows": (_int, [_vp, _int, _int, _int]),
     "sitrk_record_ptr": (_vp, [_vp, _int]),
     "sitrk_commit_record": (_int, [_vp, _int]),
     "sitrk_set_buoys": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
@@ -210,6 +211,9 @@ class Context:
         s = as_c(sic_rows, self.field_dtype, shp, "sic rows")
         self._chk(self._L.sitrk_push_record_rows(self._h, int(slot), int(j0), int(j1), _ptr(u), _ptr(v), _ptr(s)))
         self.sync()
+
+    def commit_record_rows(self, slot, j0, j1):
+        self._chk(self._L.sitrk_commit_record_rows(self._h, int(slot), int(j0), int(j1)))
 
     def push_record_dev(self, slot, dev_ptr):
         self._chk(self._L.sitrk_push_record_dev(self._h, int(slot), _vp(dev_ptr)))

@@ -335,6 +335,29 @@ SITRK_API int sitrk_push_record_rows(sitrk_t *h, int slot, int j0, int j1, const
     return SITRK_OK;
 }
 
+SITRK_API int sitrk_commit_record_rows(sitrk_t *h, int slot, int j0, int j1)
+{
+    NEED(h, "null handle");
+    NEED(h->slabs, "sitrk_commit_record_rows: call sitrk_alloc_records first");
+    NEED(slot >= 0 && slot < h->nslots, "sitrk_commit_record_rows: slot out of range");
+    NEED(j0 >= 0 && j1 <= h->Nj && j0 <= j1, "sitrk_commit_record_rows: rows out of range");
+    if (j0 == j1) return SITRK_OK;
+    HIPCHK(hipSetDevice(h->device));
+    const size_t n = (size_t)h->Nj * h->Ni, es = elem_size(h->dtype);
+    const char *sic = slab_of(h, slot) + 2 * n * es;
+    int8_t *kill = h->kill + (size_t)slot * n;
+    const int64_t cells = (int64_t)(j1 - j0) * h->Ni;
+    if (h->dtype == SITRK_F64)
+        hipLaunchKernelGGL((survive_mask_rows_kernel<double>), dim3(nblocks(cells)), dim3(kBlock), 0, h->stream, h->Nj, h->Ni, j0, j1, j0, j1,
+                           h->tmask, (const double *)sic, h->rmin_conc, kill);
+    else
+        hipLaunchKernelGGL((survive_mask_rows_kernel<float>), dim3(nblocks(cells)), dim3(kBlock), 0, h->stream, h->Nj, h->Ni, j0, j1, j0, j1,
+                           h->tmask, (const float *)sic, h->rmin_conc, kill);
+    HIPCHK(hipGetLastError());
+    h->slot_dirty[slot] = 0;
+    return SITRK_OK;
+}
+
 SITRK_API int sitrk_push_record_dev(sitrk_t *h, int slot, const void *slab_dev)
 {
     NEED(h, "null handle");
