@@ -99,6 +99,23 @@ def cpu_baseline(grid, u, v, sic, yx, ji, target_s, uv_strategy):
             "value_1core": out[1][0], "sample_1core": "%d buoys x %d records" % (out[1][1], out[1][2])}
 
 
+def cpu_baseline_check(ctx, grid, u, v, sic, yx, ji, nsteps, uv_strategy, nS=20000):
+    """cpu_baseline leg, optional part (--check): the oracle replays the run on the first nS buoys and the GPU state must
+    agree bit for bit (checker only -- nothing here is timed or fed back)."""
+    from oracle import oracle as orc
+    K = u.shape[0]
+    ref = orc.Tracker(grid, yx[:nS], ji[:nS], uv_strategy=uv_strategy, nthreads=8)
+    f64 = [(u[k].astype(np.float64), v[k].astype(np.float64), sic[k].astype(np.float64)) for k in range(K)]
+    for s in range(nsteps):
+        ref.step(s, *f64[s % K], want_out=False)
+        if s % 2000 == 1999:
+            print("check: oracle at step %d / %d" % (s + 1, nsteps), file=sys.stderr, flush=True)
+    st = ctx.fetch()
+    assert np.array_equal(st["yx"][:nS], ref.pos) and np.array_equal(st["jiT"][:nS], ref.jiT)
+    assert np.array_equal(st["alive"][:nS], ref.alive)
+    print("check OK: first %d buoys bit-exact vs oracle after %d steps" % (nS, nsteps), file=sys.stderr)
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -271,20 +288,8 @@ def main():
         nalive = int(t[0])
 
     if a.check and rank == 0:
-        from oracle import oracle as orc
-        nS = 20000
-        ref = orc.Tracker(grid, yx[:nS], ji[:nS], uv_strategy=a.uv_strategy, nthreads=8)
-        f64 = [(u[k].astype(np.float64), v[k].astype(np.float64), sic[k].astype(np.float64)) for k in range(K)]
         nchk = (a.warmup + a.steps) if per_record is None else (a.warmup + 2 * a.steps)
-        for s in range(nchk):
-            ref.step(s, *f64[s % K], want_out=False)
-            if s % 2000 == 1999:
-                print("check: oracle at step %d / %d" % (s + 1, nchk), file=sys.stderr, flush=True)
-        del f64
-        st = ctx.fetch()
-        assert np.array_equal(st["yx"][:nS], ref.pos) and np.array_equal(st["jiT"][:nS], ref.jiT)
-        assert np.array_equal(st["alive"][:nS], ref.alive)
-        print("check OK: first %d buoys bit-exact vs oracle after %d steps" % (nS, s + 1), file=sys.stderr)
+        cpu_baseline_check(ctx, grid, u, v, sic, yx, ji, nchk, a.uv_strategy)
 
     if rank == 0:
         total = float(nP) * world * a.steps

@@ -3,7 +3,7 @@
 BASELINE.json config-5 shape -- a polar 4096^2 mesh (1 km), 1e7 seeds given as (lat,lon) + (y,x) like a seeding file,
 ice mask with open water and land, hourly records.
 
-    python tools/demo_pipeline.py [--grid 4096] [--seeds 10000000] [--records 240]
+    python tests/sweeps/demo_pipeline.py [--grid 4096] [--seeds 10000000] [--records 240]
 
 Stages timed: grid upload, SeedInit (GPU locate), compaction, set_buoys (+ cell sort), record upload, tracking
 (sitrk_run, 8 records per launch), final fetch with lat/lon.  A subsample goes through the CPU oracle end to
@@ -17,7 +17,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 import sitrack_amd as sit                      # noqa: E402

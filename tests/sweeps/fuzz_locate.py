@@ -4,7 +4,7 @@ returns (same device formula, ties -> lowest flat index) on random meshes anywhe
 the pole, down to low latitudes, strongly warped -- with seeds on T-points, on F-points (exact ties), inside cells and
 far outside the mesh; a subsample is also held against the CPU oracle (glibc libm).
 
-    python tools/fuzz_locate.py [--cases 80] [--seed 0]"""
+    python tests/sweeps/fuzz_locate.py [--cases 80] [--seed 0]"""
 import argparse
 import os
 import sys
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 import sitrack_amd as sit                      # noqa: E402

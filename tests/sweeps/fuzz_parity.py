@@ -4,7 +4,7 @@ grid size and warp, velocity scale, land/ice patterns incl. NaN/huge fill values
 velocity rules, fp32/fp64 records, fused and per-record launches, re-sort cadence, tile order.  Every case must
 be bit-identical (positions, cells, alive, kill record, per-record masks on sampled records).
 
-    python tools/fuzz_parity.py [--cases 60] [--seed 0]"""
+    python tests/sweeps/fuzz_parity.py [--cases 60] [--seed 0]"""
 import argparse
 import os
 import sys
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 import sitrack_amd as sit                      # noqa: E402

@@ -81,6 +81,34 @@ def test_product_never_imports_the_oracle():
                 assert "oracle" not in txt.lower(), os.path.join(dirpath, f)
 
 
+def test_only_the_allowed_places_touch_the_oracle():
+    """oracle/ is test infrastructure: besides tests/, only __graft_entry__ (build of the checker + smoke) and bench.py's
+    cpu_baseline leg may import it."""
+    import ast
+    offenders = []
+    for dirpath, dirs, files in os.walk(ROOT):
+        dirs[:] = [d for d in dirs if d not in (".git", "tests", "oracle", "gpurun_out", "__pycache__", ".pytest_cache")]
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            path = os.path.join(dirpath, f)
+            tree = ast.parse(open(path).read())
+            for node in ast.walk(tree):
+                mods = []
+                if isinstance(node, ast.ImportFrom) and node.module:
+                    mods = [node.module]
+                elif isinstance(node, ast.Import):
+                    mods = [a.name for a in node.names]
+                if any(m == "oracle" or m.startswith("oracle.") for m in mods):
+                    offenders.append(os.path.relpath(path, ROOT))
+    assert sorted(set(offenders)) == ["__graft_entry__.py", "bench.py"], offenders
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
+        uses = any(isinstance(n, ast.ImportFrom) and n.module == "oracle" for n in ast.walk(fn))
+        assert uses == fn.name.startswith("cpu_baseline"), fn.name
+
+
 def test_get_time_span_matches_golden(golden):
     g = golden("g8_timespan.npz")
     vt = g["vtime"]
