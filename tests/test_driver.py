@@ -50,6 +50,55 @@ def test_record_windows():
     assert list(zL) == [23, 12, 23]
 
 
+def test_ncio_schema_and_roundtrip_both_backends(tmp_path, monkeypatch):
+    """ncSaveCloudBuoys / LoadNCdata / LoadNCtime / *TimeInfo with the NetCDF-3 fall-back and with the netCDF4 code path
+    (driven through a minimal stand-in for the absent package: tests/fakes/netCDF4.py)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "fakes"))
+    import netCDF4 as fake
+    sys.path.pop(0)
+    rng = np.random.default_rng(0)
+    Nt, Nb = 3, 7
+    t = np.array([850608000, 850611600, 850615200])
+    ids = (300534062025510 + np.arange(Nb)).astype(np.int64)
+    Y, X = rng.uniform(-3000, 3000, (Nt, Nb)), rng.uniform(-3000, 3000, (Nt, Nb))
+    La, Lo = rng.uniform(60, 90, (Nt, Nb)), rng.uniform(-180, 180, (Nt, Nb))
+    Y[2, 3] = X[2, 3] = La[2, 3] = Lo[2, 3] = -9999.
+    msk = np.ones((Nt, Nb), dtype='i1'); msk[2, 3] = 0
+    tp = np.tile(t[:, None], (1, Nb)); tp[2, 3] = -9999
+    for backend in (None, fake):
+        monkeypatch.setattr(ncio, "_nc4", backend)
+        f = str(tmp_path / ("NEMO-SI3_X_Y_tracking_nemoTsi3_idlSeed_%s.nc" % ("nc4" if backend else "nc3")))
+        ncio.ncSaveCloudBuoys(f, t, ids, Y, X, La, Lo, mask=msk, xtime=tp, corigin="unit-test")
+        tt, bid, ll, yx, mk, tpos = ncio.LoadNCdata(f, krec=-1, lmask=True, lGetTimePos=True)
+        assert np.array_equal(tt, t) and np.array_equal(bid, ids) and np.array_equal(mk, msk) and np.array_equal(tpos, tp)
+        assert np.array_equal(yx[..., 0], Y.astype('f4').astype('f8')) and np.array_equal(yx[..., 1], X.astype('f4').astype('f8'))
+        assert np.array_equal(ll[..., 0], La.astype('f4').astype('f8'))
+        assert np.array_equal(ll[..., 1], np.mod(Lo.astype('f4').astype('f8'), 360.))          # reference ncio.py:303
+        t1, b1, ll1, yx1 = ncio.LoadNCdata(f, krec=1)
+        assert int(t1) == t[1] and yx1.shape == (Nb, 2) and np.array_equal(yx1, yx[1])
+        assert ncio.LoadNCtime(f)[0] == Nt
+        i0, iN, name, batch, t2d = ncio.SeedFileTimeInfo(f, ltime2d=True)
+        assert (i0, iN) == (-3600 * 3, 850615200) or i0 <= 850608000      # FillValue entries drag the minimum down, as in the reference
+        assert batch == "Y"
+        with ncio._Reader(f) as r:
+            assert r.attr("time", "units") == ncio.tunits_default and r.attr("longitude", "units") == "degrees south"
+            assert r.attr("id_buoy", "units") == "ID of buoy" and r.dim("buoy") == Nb
+    # the netCDF4 branch asks for the reference's variable types, fill values and compression (ncio.py:153-171)
+    monkeypatch.setattr(ncio, "_nc4", fake)
+    made = {}
+    orig = fake.Dataset.createVariable
+
+    def spy(self, name, typ, dims, **kw):
+        made[name] = (typ, dims, kw)
+        return orig(self, name, typ, dims, **kw)
+    monkeypatch.setattr(fake.Dataset, "createVariable", spy)
+    ncio.ncSaveCloudBuoys(str(tmp_path / "a_b_c_d.nc"), t, ids, Y, X, La, Lo, mask=msk, xtime=tp)
+    assert made["id_buoy"][0] == 'i8' and made["time"][0] == 'i4' and made["mask"][0] == 'i1' and made["time_pos"][0] == 'i4'
+    for v in ("latitude", "longitude", "y_pos", "x_pos"):
+        assert made[v] == ('f4', ('time', 'buoy'), dict(fill_value=-9999., zlib=True, complevel=9))
+
+
 def _write_nc3(fname, dims, variables, attrs=None):
     from scipy.io import netcdf_file
     f = netcdf_file(fname, 'w', version=2)
