@@ -767,6 +767,19 @@ SITRK_API int sitrk_seed_init(sitrk_t *h, int64_t nP, const double *latlon, cons
         sa.nP = nP; sa.Nj = h->Nj; sa.Ni = h->Ni; sa.nbj = nbj; sa.nbi = nbi; sa.sbf = sbf; sa.nsj = nsj; sa.nsi = nsi;
         sa.latlon = d_ll; sa.ux = ux; sa.uy = uy; sa.uz = uz; sa.blk = blk; sa.sblk = sblk; sa.latT = d_lat; sa.lonT = d_lon;
         sa.kbest = kb; sa.dbest = db;
+        {
+            // largest distance the acceptance loop of NearestPoint can ever accept (locate.py:253-266 with max_itr = 10):
+            // rfnd starts at 0.5*resol (or rd_found_km) and is multiplied by 1.2 at most max_itr-2 times
+            double rmax = 2.5;
+            if (resolkm) {
+                rmax = 0.0;
+                for (size_t c = 0; c < n; c++) rmax = std::max(rmax, 0.5 * resolkm[c]);
+            }
+            const double dmax = rmax * std::pow(1.2, 8) * 1.02;              // km on the R = 6360 km Haversine sphere, +2 %
+            const double half = std::min(dmax / (2.0 * 6360.0), M_PI_2);
+            const double chord = 2.0 * std::sin(half);
+            sa.far2 = (std::isfinite(dmax) && dmax >= 0.0) ? chord * chord : __builtin_inf();
+        }
         hipLaunchKernelGGL(seed_search_kernel, dim3(nblocks(nP, kBlock / 64)), dim3(kBlock), 0, h->stream, sa);
         hipLaunchKernelGGL(seed_finish_kernel, dim3(nblocks(nP)), dim3(kBlock), 0, h->stream, nP, h->Nj, h->Ni, kb, db, d_yx,
                            resolkm ? d_res : nullptr, d_sic, h->tmask, h->geo, h->rmin_conc, 2.5, 10, d_ji, d_keep, d_why);

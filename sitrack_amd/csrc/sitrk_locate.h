@@ -138,6 +138,7 @@ struct SearchArgs {
     const double *latT, *lonT;
     uint32_t *kbest;
     double *dbest;
+    double far2;                        // chord^2 beyond which no T-point can pass NearestPoint's acceptance test
 };
 
 // squared lower bound of the chord from s to any point of the sphere (0 when s may be inside)
@@ -226,11 +227,20 @@ __global__ __launch_bounds__(kBlock) void seed_search_kernel(SearchArgs a)
     // upper bound of the minimum chord^2: the farthest point of the most promising superblock,
     // then of its most promising block
     const int nsb = a.nsj * a.nsi;
-    double ub2 = __builtin_inf();
+    double ub2 = __builtin_inf(), lbmin2 = __builtin_inf();
     int sbest = 0;
     for (int s = lane; s < nsb; s += 64) {
-        double u = sphere_ub2(sx, sy, sz, a.sblk[s]);
+        const Sphere q = a.sblk[s];
+        double u = sphere_ub2(sx, sy, sz, q);
         if (u < ub2) { ub2 = u; sbest = s; }
+        lbmin2 = fmin(lbmin2, sphere_lb2(sx, sy, sz, q));
+    }
+    // A seed farther from every superblock than the largest distance NearestPoint can accept is rejected whatever its
+    // nearest T-point is (locate.py:264-271): skip the search -- it would have to visit most of the mesh, since from far
+    // away all T-points are about equally distant.  `far2` carries a 2 % margin; closer seeds take the exact path.
+    if (wave_min(lbmin2) > a.far2) {
+        if (lane == 0) { a.kbest[p] = 0xffffffffu; a.dbest[p] = __builtin_inf(); }
+        return;
     }
     {
         const double w = wave_min(ub2);
@@ -277,6 +287,12 @@ __global__ void seed_finish_kernel(int64_t nP, int Nj, int Ni, const uint32_t *_
     if (p >= nP) return;
     const uint32_t k = kbest[p];
     const double best = dbest[p];
+    if (k == 0xffffffffu) {                              // farther than any acceptance radius (seed_search_kernel)
+        jiT[2 * p] = 0; jiT[2 * p + 1] = 0;
+        keep[p] = 0;
+        if (why) why[p] = 1;
+        return;
+    }
     const int jy = (int)(k / (uint32_t)Ni), jx = (int)(k % (uint32_t)Ni);
     double rfnd = rd_found_km;
     bool lfound = false;
