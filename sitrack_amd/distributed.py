@@ -51,21 +51,31 @@ def broadcast_record(ctx, slot, slab_host, src=0, group=None, async_op=False):
     `slab_host`: packed [u|v|siconc] numpy array on rank `src`, ignored elsewhere.
     With backend nccl the broadcast writes the resident slot directly (no staging copy).
     Returns the torch work handle when async_op, else None (stream-synchronised)."""
+    import os
     import torch
     import torch.distributed as dist
-    t = slot_tensor(ctx, slot)
+    staged = False
+    try:
+        t = slot_tensor(ctx, slot)                     # zero-copy view of the resident slot
+    except Exception:                                  # noqa: BLE001 -- e.g. a torch build without __cuda_array_interface__ import
+        t = torch.empty(ctx.slab_elems, dtype=torch.float64 if ctx.field_dtype == np.dtype(np.float64) else torch.float32,
+                        device="cuda:%d" % ctx.device)
+        staged = True
     if dist.get_rank(group) == src:
         t.copy_(torch.from_numpy(slab_host), non_blocking=False)
-    import os
     if os.environ.get("SITRK_BCAST", "") == "scatter_allgather" and not async_op and dist.get_world_size(group) > 2:
         scatter_allgather(t, src=src, group=group)
         work = None
     else:
-        work = dist.broadcast(t, src=src, group=group, async_op=async_op)
-    if async_op:
+        work = dist.broadcast(t, src=src, group=group, async_op=async_op and not staged)
+    if async_op and not staged:
         return work                    # caller: work.wait(), order the streams, then ctx.commit_record(slot)
     torch.cuda.current_stream().synchronize()
-    ctx.commit_record(slot)            # derive the record's Survive mask from the new slab
+    if staged:
+        ctx.push_record_dev(slot, t.data_ptr())        # device-to-device copy into the slot + Survive mask
+        ctx.sync()
+    else:
+        ctx.commit_record(slot)        # derive the record's Survive mask from the new slab
     return None
 
 
