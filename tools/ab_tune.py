@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
 """Interleaved A/B of libsitrk performance knobs on one GPU, one process (C3 workload).
 
-    python tools/ab_tune.py [--config c3] [--steps 200] [--rounds 5]
-Prints median / min ms per step for every knob combination; results must not depend on knobs
-(checked on the final state against the first variant)."""
+    python tools/ab_tune.py [--steps 200] [--rounds 5] [--knobs xcd_remap,nt_state] [--tiles 8x16,16x16]
+                            [--fuse 2,4,8] [--values step_block:256:512:1024] [--base fuse=1,nt_state=1]
+Knobs (sitrk_set_tuning): xcd_remap, nt_state (0/1), sort_tile (tile_j*256+tile_i), fuse (1..8), step_block
+(256/512/1024), locate_bruteforce; with `make -C sitrack_amd/csrc -B DIAG=1` also the ablation kernels
+diag_memonly / diag_nocross (--singles).  Prints median / min ms per record for every variant; results must not
+depend on knobs (checked on the final state against the first variant).  This is how the defaults in
+sitrk_internal.h were chosen."""
 import argparse
 import itertools
 import os
