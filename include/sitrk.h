@@ -70,8 +70,11 @@ int sitrk_set_grid(sitrk_t *h, int Nj, int Ni,
                    const int8_t *tmask);
 
 /* module-level constants of the reference, same defaults:
- * rdt = 3600 (si3_part_tracker.py:31), iUVstrategy = 1 (:37),
- * rmin_conc = 0.1 (sitrack/tracking.py:4) */
+ * rdt = 3600 (si3_part_tracker.py:31), iUVstrategy = 1 (:37; 0 = cell mean, 1 = nearest U/V point),
+ * rmin_conc = 0.1 (sitrack/tracking.py:4).
+ * uv_strategy = 2 is an EXTRA the reference does not have (no parity claim against it): u is interpolated linearly
+ * between the cell's left and right U-points and v between its lower and upper V-points, at the buoy's clamped
+ * projection on the segment joining them. */
 int sitrk_set_params(sitrk_t *h, double rdt, int uv_strategy, double rmin_conc);
 
 /* performance knobs; they never change results.  "xcd_remap" (0/1): each XCD walks a

@@ -341,6 +341,18 @@ int orc_seed_init(i64 nP, const double *pSG, const double *pSC,
  * Note the kill timing (:459-460 then :483-484): position and mask are written
  * BEFORE the kill test.
  * ---------------------------------------------------------------------- */
+/* EXTRA velocity rule (uv_strategy = 2), not in the reference: linear interpolation between the two points that
+ * carry the component, at the buoy's clamped projection on the segment joining them.  Restated here only so that the
+ * GPU implementation of the extra has an independent check; there is no reference behaviour to pin it to. */
+static double lerp_on_segment(const double *P, const double *A, const double *B, double fa, double fb)
+{
+    const double dy = B[0] - A[0], dx = B[1] - A[1];
+    const double den = dy * dy + dx * dx;
+    double s = ((P[0] - A[0]) * dy + (P[1] - A[1]) * dx) / den;
+    s = (s < 0.0) ? 0.0 : ((s > 1.0) ? 1.0 : s);
+    return (1.0 - s) * fa + s * fb;
+}
+
 static int advect_one(i64 p, i64 jrec, double rdt, int uv_strategy, double rmin_conc,
                       i64 Nj, i64 Ni,
                       const double *Yf, const double *Xf, const double *Yu, const double *Xu,
@@ -370,6 +382,14 @@ static int advect_one(i64 p, i64 jrec, double rdt, int uv_strategy, double rmin_
     if (uv_strategy == 0) {                                 /* :423-425 */
         zU = 0.5 * (AT(u, jT, iT) + AT(u, jT, iT - 1));
         zV = 0.5 * (AT(v, jT, iT) + AT(v, jT - 1, iT));
+    } else if (uv_strategy == 2) {                          /* extra, see lerp_on_segment */
+        double P[2] = { ry, rx };
+        double Va[2] = { AT(Yv, jT - 1, iT), AT(Xv, jT - 1, iT) };
+        double Vb[2] = { AT(Yv, jT, iT), AT(Xv, jT, iT) };
+        double Ua[2] = { AT(Yu, jT, iT - 1), AT(Xu, jT, iT - 1) };
+        double Ub[2] = { AT(Yu, jT, iT), AT(Xu, jT, iT) };
+        zU = lerp_on_segment(P, Ua, Ub, AT(u, jT, iT - 1), AT(u, jT, iT));
+        zV = lerp_on_segment(P, Va, Vb, AT(v, jT - 1, iT), AT(v, jT, iT));
     } else {                                                /* :427-441 */
         double P[2] = { ry, rx };
         double F[2] = { AT(Yf, jT, iT), AT(Xf, jT, iT) };

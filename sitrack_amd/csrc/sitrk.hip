@@ -176,7 +176,8 @@ SITRK_API int sitrk_set_grid(sitrk_t *h, int Nj, int Ni, const double *Yf, const
 SITRK_API int sitrk_set_params(sitrk_t *h, double rdt, int uv_strategy, double rmin_conc)
 {
     NEED(h, "null handle");
-    NEED(uv_strategy == 0 || uv_strategy == 1, "sitrk_set_params: uv_strategy must be 0 (cell mean) or 1 (nearest U/V point)");
+    NEED(uv_strategy >= 0 && uv_strategy <= 2,
+         "sitrk_set_params: uv_strategy must be 0 (cell mean), 1 (nearest U/V point) or 2 (linear interpolation, not in the reference)");
     NEED(rdt > 0.0, "sitrk_set_params: rdt must be > 0");
     if (rmin_conc != h->rmin_conc) memset(h->slot_dirty, 1, sizeof(h->slot_dirty));     // masks depend on it
     h->rdt = rdt; h->uv_strategy = uv_strategy; h->rmin_conc = rmin_conc;
@@ -475,6 +476,9 @@ static void launch_step_b(sitrk_ctx *h, const StepArgs &a)
     if (h->uv_strategy == 1) {
         if (h->windowed) hipLaunchKernelGGL((advect_step_kernel<FT, 1, true, BLOCK>), grid, block, 0, h->stream, a);
         else hipLaunchKernelGGL((advect_step_kernel<FT, 1, false, BLOCK>), grid, block, 0, h->stream, a);
+    } else if (h->uv_strategy == 2) {
+        if (h->windowed) hipLaunchKernelGGL((advect_step_kernel<FT, 2, true, BLOCK>), grid, block, 0, h->stream, a);
+        else hipLaunchKernelGGL((advect_step_kernel<FT, 2, false, BLOCK>), grid, block, 0, h->stream, a);
     } else {
         if (h->windowed) hipLaunchKernelGGL((advect_step_kernel<FT, 0, true, BLOCK>), grid, block, 0, h->stream, a);
         else hipLaunchKernelGGL((advect_step_kernel<FT, 0, false, BLOCK>), grid, block, 0, h->stream, a);
@@ -534,6 +538,9 @@ static void launch_run(sitrk_ctx *h, const RunArgs &ra)
         if (h->uv_strategy == 1) {                                                                        \
             if (h->windowed) hipLaunchKernelGGL((KERNEL<FT, 1, true>), grid, block, 0, h->stream, ra);    \
             else hipLaunchKernelGGL((KERNEL<FT, 1, false>), grid, block, 0, h->stream, ra);               \
+        } else if (h->uv_strategy == 2) {                                                                 \
+            if (h->windowed) hipLaunchKernelGGL((KERNEL<FT, 2, true>), grid, block, 0, h->stream, ra);    \
+            else hipLaunchKernelGGL((KERNEL<FT, 2, false>), grid, block, 0, h->stream, ra);               \
         } else {                                                                                          \
             if (h->windowed) hipLaunchKernelGGL((KERNEL<FT, 0, true>), grid, block, 0, h->stream, ra);    \
             else hipLaunchKernelGGL((KERNEL<FT, 0, false>), grid, block, 0, h->stream, ra);               \

@@ -37,6 +37,19 @@ __device__ __forceinline__ bool intersect2seg(pt A, pt B, pt C, pt D)
     return (ccw(A, C, D) != ccw(B, C, D)) && (ccw(A, B, C) != ccw(A, B, D));
 }
 
+// EXTRA, not in the reference (iUVstrategy = 2): linear interpolation of a C-grid component between the two points
+// that carry it in the cell -- u between the left and right U-points, v between the lower and upper V-points -- at the
+// buoy's projection on the segment joining them, clamped to the segment.  The reference's rules are piecewise constant
+// (nearest point, or cell mean); this is the "interpolated" velocity BASELINE.json's north_star speaks of.
+__device__ __forceinline__ double lerp_on_segment(pt P, pt A, pt B, double fa, double fb)
+{
+    const double dy = B.y - A.y, dx = B.x - A.x;
+    const double den = dy * dy + dx * dx;
+    double s = ((P.y - A.y) * dy + (P.x - A.x) * dx) / den;
+    s = (s < 0.0) ? 0.0 : ((s > 1.0) ? 1.0 : s);
+    return (1.0 - s) * fa + s * fb;
+}
+
 // one edge visit of the ray cast of IsInsideQuadrangle (locate.py:66-76);
 // `xints` is carried between visits when the edge is horizontal (:63,71-73)
 __device__ __forceinline__ void ray_edge(double y, double x, pt z1, pt z2, double &xints, bool &inside)

@@ -227,6 +227,9 @@ __device__ __forceinline__ bool advance_record(const StepArgs &a, const FT *__re
     if (UVS == 0) {                                      // :423-425
         zU = 0.5 * ((double)u[k] + (double)u[k - 1]);
         zV = 0.5 * ((double)v[k] + (double)v[k - Ni]);
+    } else if (UVS == 2) {                               // extra: linear interpolation (not in the reference)
+        zU = lerp_on_segment(P, a.geo[k - 1].u, g11.u, (double)u[k - 1], (double)u[k]);
+        zV = lerp_on_segment(P, a.geo[k - Ni].v, g11.v, (double)v[k - Ni], (double)v[k]);
     } else {                                             // :427-441
         const pt U10 = a.geo[k - 1].u;                   // U[jT,iT-1]
         const pt V01 = a.geo[k - Ni].v;                  // V[jT-1,iT]
@@ -355,6 +358,9 @@ __global__ __launch_bounds__(kBlock, 5) void advect_run_kernel(RunArgs ra)
         if (UVS == 0) {                                  // :423-425
             zU = 0.5 * ((double)u[x.k] + (double)u[x.k - 1]);
             zV = 0.5 * ((double)v[x.k] + (double)v[x.k - Ni]);
+        } else if (UVS == 2) {                           // extra: linear interpolation (not in the reference)
+            zU = lerp_on_segment(P, x.U10, x.U11, (double)u[x.k - 1], (double)u[x.k]);
+            zV = lerp_on_segment(P, x.V01, x.V11, (double)v[x.k - Ni], (double)v[x.k]);
         } else {                                         // :427-441
             const double u1 = (double)u[x.k], u0 = (double)u[x.k - 1];
             const double v1 = (double)v[x.k], v0 = (double)v[x.k - Ni];

@@ -54,7 +54,8 @@ def parse_args(argv=None):
     ap.add_argument('-N', '--ncnf', default='NANUK4', help='name of the horizontak NEMO config used')
     ap.add_argument('-p', '--plot', type=int, default=0, help='how often, in terms of model records, we plot the positions on a map')
     ap.add_argument('--device', type=int, default=0, help='GPU to use (extra)')
-    ap.add_argument('--uv-strategy', type=int, default=1, choices=(0, 1), help='iUVstrategy of the reference, default 1 (extra)')
+    ap.add_argument('--uv-strategy', type=int, default=1, choices=(0, 1, 2),
+                    help='iUVstrategy of the reference (0 cell mean, 1 nearest U/V point = default); 2 = linear interpolation, an extra the reference does not have')
     ap.add_argument('--full-records', action='store_true',
                     help='read and upload whole records (under torchrun: rank 0 reads, RCCL broadcast) instead of only the rows '
                          'each rank\'s buoys can touch (extra; same results)')
@@ -139,7 +140,7 @@ def main(argv=None):
 
     ctx = _lib.Context(a.device if comm.world == 1 else comm.device)
     imaskt, xlatT, xlonT, xYt, xXt, xYf, xXf, xResKM = ncio.GetModelGrid(cf_mm, ctx)
-    if iUVstrategy == 1:
+    if iUVstrategy >= 1:
         xYv, xXv, xYu, xXu = ncio.GetModelUVGrid(cf_mm, ctx)
     else:
         xYv, xXv, xYu, xXu = xYf, xXf, xYf, xXf     # never read by the cell-mean rule

@@ -20,14 +20,14 @@ from sitrack_amd import synthetic as syn       # noqa: E402
 from oracle import oracle as orc               # noqa: E402
 
 
-def one_case(rng, idx):
+def one_case(rng, idx, nstrat=2):
     Nj, Ni = int(rng.integers(24, 260)), int(rng.integers(24, 300))
     warp = float(rng.choice([0.0, 0.5, 1.0]))
     dkm = float(rng.choice([1.0, 4.0, 12.5]))
     K = int(rng.integers(1, 9))
     nP = int(rng.integers(1, 40000))
     Nt = int(rng.integers(1, 60))
-    strat = int(rng.integers(0, 2))
+    strat = int(rng.integers(0, nstrat))       # 0/1 = the reference's rules; 2 = the linear-interpolation extra
     fdt = np.float64 if rng.random() < 0.25 else np.float32
     umax = float(rng.choice([0.1, 0.3, 0.9, 2.5])) * dkm / 4.0
     grid = syn.make_grid(Nj, Ni, dkm=dkm, warp=warp)
@@ -92,11 +92,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--with-extra", action="store_true", help="also draw uv_strategy 2 (not in the reference)")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     t0 = time.time()
     for idx in range(a.cases):
-        print("case %3d: %s" % (idx, one_case(rng, idx)), flush=True)
+        print("case %3d: %s" % (idx, one_case(rng, idx, 3 if a.with_extra else 2)), flush=True)
     print("ALL %d CASES BIT-IDENTICAL (%.1f s)" % (a.cases, time.time() - t0), flush=True)
 
 

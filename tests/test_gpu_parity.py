@@ -208,6 +208,31 @@ def test_rim_cells_and_negative_index_wrap():
     trk.close()
 
 
+def test_extra_linear_interpolation_rule():
+    """uv_strategy = 2 is not in the reference; the GPU implementation is held against its independent C restatement,
+    and it must differ from the two reference rules while staying between the two face values."""
+    grid = syn.make_grid(96, 112, dkm=4.0, warp=1.0)
+    K, Nt = 3, 20
+    u, v, sic = syn.make_fields(grid, K=K, seed=31, umax=0.6, drift=0.2, ripple=0.15)
+    _, yx = syn.make_buoys(grid, 12000, seed=9, frac=0.7)
+    out = {}
+    for strat in (1, 2):
+        trk = make_tracker(grid, grid["tmask"], K, iUVstrategy=strat)
+        found, ji, _ = sit.FindContainingCell(yx, syn.nearest_t_plane(grid, yx), ctx=trk.ctx)
+        trk.set_buoys(yx[found], ji[found])
+        for k in range(K):
+            trk.load_record(k, u[k], v[k], sic[k])
+        ref = orc.Tracker(grid, yx[found], ji[found], uv_strategy=strat, nthreads=8)
+        for s in range(Nt):
+            trk.step(s, s % K) if s % 2 else trk.ctx.run(s % K, s, 1)
+            rp, rm = ref.step(s, u[s % K], v[s % K], sic[s % K])
+        st = trk.state()
+        assert np.array_equal(st["yx"], ref.pos) and np.array_equal(st["vJIt"], ref.jiT) and np.array_equal(st["iAlive"], ref.alive)
+        out[strat] = st["yx"]
+        trk.close()
+    assert not np.array_equal(out[1], out[2]) and np.abs(out[1] - out[2]).max() < 30.0
+
+
 def test_fill_values_nan_and_empty_windows():
     """Land points of NEMO output carry raw fill data (reference si3_part_tracker.py:372-374 assigns masked slabs
     into plain arrays): huge values, NaN.  Buoys that pick them up must behave exactly like in the reference
@@ -495,6 +520,6 @@ def test_errors(ctx):
     with pytest.raises(sit.SitrkError):
         ctx.step(2, 0)
     with pytest.raises(sit.SitrkError):
-        ctx.set_params(3600., 2, 0.1)
+        ctx.set_params(3600., 3, 0.1)           # 0, 1 = the reference's rules, 2 = the extra
     with pytest.raises(ValueError):
         ctx.push_record(0, np.zeros((3, 3)), np.zeros((3, 3)), np.zeros((3, 3)))
