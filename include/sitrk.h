@@ -173,7 +173,9 @@ int sitrk_seed_init(sitrk_t *h, int64_t nP, const double *latlon, const double *
 /* ---- predicate probes ------------------------------------------------------
  * The device-side predicates of the hot path evaluated on plain arrays, so that each one can be held
  * against the reference function it restates (parity tests):
- *   sitrk_eval_inside    IsInsideQuadrangle (sitrack/locate.py:49-78): pts (n,2) [y,x], quads (n,4,2)
+ *   sitrk_eval_inside    IsInsideQuadrangle (sitrack/locate.py:49-78): pts (n,2) [y,x], quads (n,4,2).  Evaluated in the
+ *                        division-free form of the hot loop AND in the plain form: 0/1, +2 if the two ever disagreed
+ *   sitrk_eval_euler     r + (vel * rdt) / 1000. (si3_part_tracker.py:452-458) as the hot loop evaluates it
  *   sitrk_eval_intersect intersect2Seg and _ccw_(A,B,C) (sitrack/tracking.py:44-58): segs (n,4,2) = A,B,C,D; ccw_abc may be NULL
  *   sitrk_eval_crossing  CrossedEdge + NewHostCell + UpdtInd4NewCell (tracking.py:182-305) on the current grid for a
  *                        move P1 -> P2 out of host cell jiT (n,2): new vJIt and, if codes != NULL, (n,2) = the return
@@ -181,6 +183,7 @@ int sitrk_seed_init(sitrk_t *h, int64_t nP, const double *latlon, const double *
  *   sitrk_survive_mask   Survive (tracking.py:62-93) for every cell of the current grid with the given (Nj,Ni) fp64
  *                        ice concentration and the current rmin_conc: 1 = kill */
 int sitrk_eval_inside(sitrk_t *h, int64_t n, const double *pts, const double *quads, int8_t *inside);
+int sitrk_eval_euler(sitrk_t *h, int64_t n, const double *r, const double *vel, double rdt, double *out);
 int sitrk_eval_intersect(sitrk_t *h, int64_t n, const double *segs, int8_t *intersect, int8_t *ccw_abc);
 int sitrk_eval_crossing(sitrk_t *h, int64_t n, const double *P1, const double *P2, const int32_t *jiT, int32_t *jiT_new,
                         int32_t *codes);

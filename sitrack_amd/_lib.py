@@ -52,6 +52,7 @@ _SIGNATURES = {
     "sitrk_find_cells": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "sitrk_seed_init": (_int, [_vp, _i64] + [_vp] * 9),
     "sitrk_eval_inside": (_int, [_vp, _i64, _vp, _vp, _vp]),
+    "sitrk_eval_euler": (_int, [_vp, _i64, _vp, _vp, _dbl, _vp]),
     "sitrk_eval_intersect": (_int, [_vp, _i64, _vp, _vp, _vp]),
     "sitrk_eval_crossing": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "sitrk_survive_mask": (_int, [_vp, _vp, _vp]),
@@ -322,7 +323,17 @@ class Context:
         quads = as_c(quads, np.float64, (n, 4, 2), "quads")
         out = np.empty(n, dtype=np.int8)
         self._chk(self._L.sitrk_eval_inside(self._h, n, _ptr(pts), _ptr(quads), _ptr(out)))
+        if (out & 2).any():
+            raise SitrkError("eval_inside: the division-free cell test and the plain one disagree for %d point(s), first at %d"
+                             % (int((out & 2).astype(bool).sum()), int(np.flatnonzero(out & 2)[0])))
         return out.astype(bool)
+
+    def eval_euler(self, r, vel, rdt=3600.):
+        r = as_c(r, np.float64)
+        vel = as_c(vel, np.float64, r.shape, "vel")
+        out = np.empty_like(r)
+        self._chk(self._L.sitrk_eval_euler(self._h, r.size, _ptr(r), _ptr(vel), float(rdt), _ptr(out)))
+        return out
 
     def eval_intersect(self, segs):
         segs = as_c(segs, np.float64)

@@ -168,6 +168,15 @@ SITRK_API int sitrk_set_grid(sitrk_t *h, int Nj, int Ni, const double *Yf, const
     hipLaunchKernelGGL(build_geo_kernel, dim3(nblocks((int64_t)n)), dim3(kBlock), 0, h->stream, n, s, s + n, s + 2 * n, s + 3 * n,
                        s + 4 * n, s + 5 * n, h->geo);
     HIPCHK(hipGetLastError());
+    // margin scale of the division-free cell test: every vertex coordinate is <= mg in magnitude
+    // (a non-finite vertex makes it inf/NaN: nothing is decided by the filter and the plain test runs)
+    double mg = 0.0;
+    for (size_t k = 0; k < n; k++) {
+        const double ay = fabs(Yf[k]), ax = fabs(Xf[k]);
+        if (!(ay <= mg)) mg = ay;
+        if (!(ax <= mg)) mg = ax;
+    }
+    h->eps_mg = 0x1p-48 * mg;
     HIPCHK(hipStreamSynchronize(h->stream));
     h->Nj = Nj; h->Ni = Ni;
     return SITRK_OK;
@@ -518,7 +527,7 @@ SITRK_API int sitrk_step(sitrk_t *h, int slot, int jrec)
     BuoyState &s = h->st[h->cur];
     StepArgs a;
     a.nP = h->nP; a.tune = h->tune; a.Nj = h->Nj; a.Ni = h->Ni; a.jrec = jrec;
-    a.rdt = h->rdt; a.rmin_conc = h->rmin_conc;
+    a.rdt = h->rdt; a.rmin_conc = h->rmin_conc; a.eps_mg = h->eps_mg;
     a.geo = h->geo; a.kill = h->kill + (size_t)slot * n;
     a.u = slab; a.v = slab + n * es;
     a.pos = s.pos; a.cell = s.cell; a.kill_rec = s.kill_rec; a.first = s.first; a.last = s.last;
@@ -578,7 +587,7 @@ SITRK_API int sitrk_run(sitrk_t *h, int slot0, int jrec0, int nsteps)
         BuoyState &s = h->st[h->cur];
         RunArgs ra;
         ra.s.nP = h->nP; ra.s.tune = h->tune; ra.s.Nj = h->Nj; ra.s.Ni = h->Ni; ra.s.jrec = jrec0 + k;
-        ra.s.rdt = h->rdt; ra.s.rmin_conc = h->rmin_conc; ra.s.geo = h->geo; ra.s.kill = nullptr; ra.s.u = ra.s.v = nullptr;
+        ra.s.rdt = h->rdt; ra.s.rmin_conc = h->rmin_conc; ra.s.eps_mg = h->eps_mg; ra.s.geo = h->geo; ra.s.kill = nullptr; ra.s.u = ra.s.v = nullptr;
         ra.s.pos = s.pos; ra.s.cell = s.cell; ra.s.kill_rec = s.kill_rec; ra.s.first = s.first; ra.s.last = s.last;
         ra.nrec = m;
         for (int r = 0; r < m; r++) {
@@ -821,6 +830,27 @@ SITRK_API int sitrk_eval_inside(sitrk_t *h, int64_t n, const double *pts, const 
                        (int8_t *)(s + b_p + b_q));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(inside, s + b_p + b_q, (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SITRK_OK;
+}
+
+SITRK_API int sitrk_eval_euler(sitrk_t *h, int64_t n, const double *r, const double *vel, double rdt, double *out)
+{
+    NEED(h, "null handle");
+    NEED(n >= 0, "sitrk_eval_euler: n < 0");
+    if (n == 0) return SITRK_OK;
+    NEED(r && vel && out, "sitrk_eval_euler: null array");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t b = align256((size_t)n * sizeof(double));
+    int rc = ensure_scratch(h, 3 * b);
+    if (rc) return rc;
+    char *s = (char *)h->scratch;
+    HIPCHK(hipMemcpyAsync(s, r, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(s + b, vel, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(eval_euler_kernel, dim3(nblocks(n)), dim3(kBlock), 0, h->stream, n, (const double *)s, (const double *)(s + b),
+                       rdt, (double *)(s + 2 * b));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, s + 2 * b, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return SITRK_OK;
 }

@@ -78,6 +78,73 @@ __device__ __forceinline__ bool inside_quad(double y, double x, pt q0, pt q1, pt
     return inside;
 }
 
+// ---------------------------------------------------------------------------
+// Division-free evaluation of the same two results for the fused loop (advect_run_kernel), which is bound by
+// VALU issue: an fp64 division is an 11-instruction sequence on gfx950.  Both replacements return, for every
+// input, exactly what the expressions above return; the arguments are in DESIGN.md section 3.1.
+// ---------------------------------------------------------------------------
+
+// x / 1000. , correctly rounded, without a division.
+//   z = RN(1/1000);  q = RN(x z);  r = x - 1000 q (exact in an fma);  result = RN(q + r z) = RN(v + (v-q) e_z),  v = x/1000.
+// |v-q| <= 2u|v| and |e_z| <= u (u = 2^-53), so the argument of the last rounding is within 2^-105 |v| of v, while
+// x/1000 = X 2^e / (8 * 125) is never closer than 2^-61 |v| to a midpoint of two doubles (125 (2M+1) is odd, X 2^g is
+// even) -> the rounding lands where RN(v) does.  Needs no over/underflow in q, r: guaranteed for 2^-900 <= |x| < 2^900;
+// everything else (zeros with their sign, subnormals, huge values, inf, NaN) takes the division.
+__device__ __forceinline__ double div1000(double x)
+{
+    const double z = 0x1.0624dd2f1a9fcp-10;                       // RN(1/1000)
+    const unsigned e = ((unsigned)__double2hiint(x) >> 20) & 0x7ffu;
+    const double q = x * z;
+    const double r = __builtin_fma(-q, 1000., x);
+    double f = __builtin_fma(r, z, q);
+    if (__builtin_expect(!((e - 123u) < 1800u), 0)) {
+        double t = x;
+        asm volatile("" : "+v"(t));                               // keeps the division in a branch of its own (not if-converted)
+        f = t / 1000.;
+    }
+    return f;
+}
+
+// IsInsideQuadrangle without the divisions.  Per edge A->B the reference toggles when
+//     y in (min(Ay,By), max(Ay,By)]  and  x <= max(Ax,Bx)  and  ( Ax == Bx  or  x <= X ),
+//     X = RN(RN(RN(a b) / c) + Ax),   a = RN(y-Ay), b = RN(Bx-Ax), c = RN(By-Ay)
+// (the stale `xints` of a horizontal edge is never read: such an edge fails the strict y-range test).
+//  * the range tests are rewritten on the vertices: (y > Ay) != (y > By), (x <= Ax) | (x <= Bx) - identities for
+//    finite vertices, and one comparison per vertex instead of min/max per edge;
+//  * sign(x - X) is taken from E = fma(RN(x-Ax), c, -RN(a b)) whenever |E| > |c| * 32u (|x| + Mg), Mg >= every
+//    |vertex coordinate|: x - X = E'/c - eta with |eta| <= u (|x| + 6.01 Mg) (|a| <= |c| inside the y-range bounds the
+//    quotient by |b|), so beyond that margin E/c and x - X have the same sign and the toggle is (E < 0) == (y > Ay)
+//    (c > 0 <=> y > Ay there).  Ax == Bx needs no case of its own (x < Ax decides, x == Ax is not decided);
+//  * a lane with any edge not decided that way (within ~1e-11 km of the edge, or non-finite) re-evaluates the
+//    whole test with inside_quad() above;
+//  * each edge sits in a branch of its own (the empty asm keeps it from being if-converted): an edge no lane of the
+//    wave is level with costs nothing, as in the plain form.
+// `eps_mg` = 2^-48 * Mg (sitrk_set_grid).
+__device__ __forceinline__ bool inside_quad_hot(double y, double x, pt q0, pt q1, pt q2, pt q3, double eps_mg)
+{
+    const double mx = __builtin_fma(fabs(x), 0x1p-48, eps_mg);
+    const bool g0 = y > q0.y, g1 = y > q1.y, g2 = y > q2.y, g3 = y > q3.y;
+    const bool l0 = x <= q0.x, l1 = x <= q1.x, l2 = x <= q2.x, l3 = x <= q3.x;
+    bool inside = false, undecided = false;
+#define SITRK_EDGE(A, B, gA, gB, lA, lB)                                              \
+    if ((gA != gB) & (lA | lB)) {                                                     \
+        double c = B.y - A.y;                                                         \
+        asm volatile("" : "+v"(c));                                                   \
+        const double p = (y - A.y) * (B.x - A.x);                                     \
+        const double E = __builtin_fma(x - A.x, c, -p);                               \
+        const bool dec = fabs(E) > __builtin_fma(fabs(c), mx, 0x1p-1000);             \
+        undecided |= !dec;                                                            \
+        inside ^= dec & ((__double2hiint(E) < 0) == gA);                              \
+    }
+    SITRK_EDGE(q0, q1, g0, g1, l0, l1)
+    SITRK_EDGE(q1, q2, g1, g2, l1, l2)
+    SITRK_EDGE(q2, q3, g2, g3, l2, l3)
+    SITRK_EDGE(q3, q0, g3, g0, l3, l0)
+#undef SITRK_EDGE
+    if (undecided) inside = inside_quad(y, x, q0, q1, q2, q3);
+    return inside;
+}
+
 // Python-style index: a negative index wraps, as numpy does for the reference
 // (e.g. pY[jbl-1,ibl] with jbl = 0, tracking.py:219).  Indices >= n cannot occur
 // for the cells the library accepts (1 <= jT <= Nj-2, 1 <= iT <= Ni-2).

@@ -41,6 +41,7 @@ struct sitrk_ctx {
     double rdt = 3600.0;
     int uv_strategy = 1;
     double rmin_conc = 0.1;
+    double eps_mg = 0.0;                // 2^-48 * max |Yf|,|Xf| (inside_quad_hot)
     // performance knobs and their measured defaults (tools/ab_tune.py on MI355X, C3):
     // non-temporal state streams -2 %, tile-major 8x16 cell order -8 %, XCD-chunked block order +5 % (off)
     int tune = sitrk::TUNE_NT_STATE;    // TUNE_* bits

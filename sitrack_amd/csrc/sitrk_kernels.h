@@ -188,12 +188,28 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
+// The fused loop evaluates `/1000.` and IsInsideQuadrangle without fp64 divisions (sitrk_geom.h: div1000,
+// inside_quad_hot - same results for every input): 0.111 -> 0.101 ms per record on C3.  The one-record kernel is
+// bound by memory latency, not by issue, and was measured 4-6 % SLOWER with them (and with pinned loads): it keeps
+// the plain forms.  `make EXACTDIV=1` builds the plain forms everywhere for A/B timing.
+#ifdef SITRK_EXACT_DIV
+#define SITRK_DIV1000(x) ((x) / 1000.)
+#define SITRK_INSIDE(y, x, q0, q1, q2, q3, eps) inside_quad(y, x, q0, q1, q2, q3)
+#else
+#define SITRK_DIV1000(x) div1000(x)
+#define SITRK_INSIDE(y, x, q0, q1, q2, q3, eps) inside_quad_hot(y, x, q0, q1, q2, q3, eps)
+#endif
+
+// A value that must be loaded where the source loads it: the empty asm is a use the compiler cannot move the load below.
+template <typename T> __device__ __forceinline__ void pin_load(T &v) { asm volatile("" : "+v"(v)); }
+
 struct StepArgs {
     int64_t nP;
     int tune;
     int Nj, Ni;
     int jrec;
     double rdt, rmin_conc;
+    double eps_mg;                      // 2^-48 * max |F-point coordinate| : margin scale of inside_quad_hot
     const CellGeo *geo;
     const int8_t *kill;                 // the record's Survive mask (survive_mask_kernel)
     const void *u, *v;
@@ -233,7 +249,8 @@ __device__ __forceinline__ bool advance_record(const StepArgs &a, const FT *__re
     } else {                                             // :427-441
         const pt U10 = a.geo[k - 1].u;                   // U[jT,iT-1]
         const pt V01 = a.geo[k - Ni].v;                  // V[jT-1,iT]
-        // all four candidates are loaded up front: no load depends on a predicate
+        // (the compiler sinks the two "other side" loads into the branch that selects them: a wave where no buoy
+        // picks the far point skips them, measured faster here than loading all four up front)
         const double u1 = (double)u[k], u0 = (double)u[k - 1];
         const double v1 = (double)v[k], v0 = (double)v[k - Ni];
         const bool llum1 = intersect2seg(P, g11.f, V01, g11.v);
@@ -362,22 +379,24 @@ __global__ __launch_bounds__(kBlock, 5) void advect_run_kernel(RunArgs ra)
             zU = lerp_on_segment(P, x.U10, x.U11, (double)u[x.k - 1], (double)u[x.k]);
             zV = lerp_on_segment(P, x.V01, x.V11, (double)v[x.k - Ni], (double)v[x.k]);
         } else {                                         // :427-441
-            const double u1 = (double)u[x.k], u0 = (double)u[x.k - 1];
-            const double v1 = (double)v[x.k], v0 = (double)v[x.k - Ni];
+            // all four candidates are requested up front (pin_load: none is sunk into the branch that selects it)
+            FT fu1 = u[x.k], fu0 = u[x.k - 1];
+            FT fv1 = v[x.k], fv0 = v[x.k - Ni];
             // intersect2Seg(P,F,C,D) = (ccw(P,C,D) != ccw(F,C,D)) and (ccw(P,F,C) != ccw(P,F,D)); ccw(F,C,D) is per cell
             const bool llum1 = (ccw(P, x.V01, x.V11) != x.sFV) && (ccw(P, x.F11, x.V01) != ccw(P, x.F11, x.V11));
             const bool llvm1 = (ccw(P, x.U10, x.U11) != x.sFU) && (ccw(P, x.F11, x.U10) != ccw(P, x.F11, x.U11));
-            zU = llum1 ? u0 : u1;
-            zV = llvm1 ? v0 : v1;
+            pin_load(fu0); pin_load(fv0);
+            zU = llum1 ? (double)fu0 : (double)fu1;
+            zV = llvm1 ? (double)fv0 : (double)fv1;
         }
         const double dx = zU * a.rdt;                    // :452-458
         const double dy = zV * a.rdt;
         pt Pn;
-        Pn.x = P.x + dx / 1000.;
-        Pn.y = P.y + dy / 1000.;
+        Pn.x = P.x + SITRK_DIV1000(dx);
+        Pn.y = P.y + SITRK_DIV1000(dy);
         moved = true;
         bool killed = false;
-        if (!inside_quad(Pn.y, Pn.x, x.F00, x.F01, x.F11, x.F10)) {      // :466-484
+        if (!SITRK_INSIDE(Pn.y, Pn.x, x.F00, x.F01, x.F11, x.F10, a.eps_mg)) {      // :466-484
             c = resolve_crossing(P, Pn, x.F00, x.F01, x.F11, x.F10, cell_j(c), cell_i(c), Nj, Ni, a.geo, ra.kill[r], killed);
             if (!killed) load_ctx(a, c, x);
         }
@@ -455,7 +474,24 @@ __global__ void eval_inside_kernel(int64_t n, const pt *__restrict__ pts, const 
 {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    out[k] = inside_quad(pts[k].y, pts[k].x, quads[4 * k], quads[4 * k + 1], quads[4 * k + 2], quads[4 * k + 3]) ? 1 : 0;
+    const pt q0 = quads[4 * k], q1 = quads[4 * k + 1], q2 = quads[4 * k + 2], q3 = quads[4 * k + 3];
+    // the hot loop's division-free form, with the margin scale of this quad alone; bit 1 flags a disagreement with
+    // the plain form (never set: the tests compare the byte with 0/1)
+    const double mg = fmax(fmax(fmax(fabs(q0.x), fabs(q1.x)), fmax(fabs(q2.x), fabs(q3.x))),
+                           fmax(fmax(fabs(q0.y), fabs(q1.y)), fmax(fabs(q2.y), fabs(q3.y))));
+    const bool hot = inside_quad_hot(pts[k].y, pts[k].x, q0, q1, q2, q3, 0x1p-48 * mg);
+    const bool ref = inside_quad(pts[k].y, pts[k].x, q0, q1, q2, q3);
+    out[k] = (hot ? 1 : 0) | (hot != ref ? 2 : 0);
+}
+
+// r + (vel * rdt) / 1000. as the hot loop evaluates it (si3_part_tracker.py:452-458)
+__global__ void eval_euler_kernel(int64_t n, const double *__restrict__ r, const double *__restrict__ vel, double rdt,
+                                  double *__restrict__ out)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const double d = vel[k] * rdt;
+    out[k] = r[k] + SITRK_DIV1000(d);
 }
 
 __global__ void eval_intersect_kernel(int64_t n, const pt *__restrict__ segs, int8_t *__restrict__ inter, int8_t *__restrict__ ccw_abc)

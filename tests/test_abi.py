@@ -56,6 +56,16 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
         assert r.returncode == 3 and "no HIP device" in r.stdout, r.stdout + r.stderr
 
 
+def test_constant_division_identity_on_cpu(tmp_path):
+    """The hot loop evaluates `/1000.` as mul + 2 fma (sitrk_geom.h::div1000).  Same IEEE operations on the host:
+    random values, the values closest to rounding midpoints, binade edges - all equal to the true quotient."""
+    exe = str(tmp_path / "div1000_check")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tests", "c", "div1000_check.c"), "-lm"],
+                   check=True)
+    r = subprocess.run([exe, "4000000"], capture_output=True, text=True)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.gpu
 def test_c_consumer_steps_three_buoys(tmp_path):
     r = subprocess.run([_build_c_consumer(tmp_path)], capture_output=True, text=True)

@@ -208,6 +208,79 @@ def test_rim_cells_and_negative_index_wrap():
     trk.close()
 
 
+def _step_ulps(x, k):
+    for _ in range(abs(k)):
+        x = np.nextafter(x, np.inf if k > 0 else -np.inf)
+    return x
+
+
+def test_division_free_cell_test_at_the_edges(ctx):
+    """The hot loop decides IsInsideQuadrangle without dividing unless the buoy is within ~1e-11 km of an edge
+    (sitrk_geom.h::inside_quad_hot).  Points ON the reference's own `xints`, a few ulps either side of it, on
+    vertices and on the y of vertices, for warped, regular (vertical/horizontal edges) and far-from-origin cells:
+    identical to the oracle, and the probe itself reports any disagreement with the plain form."""
+    rng = np.random.default_rng(5)
+    n = 6000
+    quads = np.empty((n, 4, 2))
+    for k in range(n):
+        cy, cx = rng.uniform(-4000, 4000, 2)
+        d = rng.choice([0.8, 4.0, 12.0])
+        w = 0.0 if k % 3 == 0 else 0.25 * d                       # every third cell is an exact rectangle
+        base = np.array([[0, 0], [0, d], [d, d], [d, 0]], dtype=np.float64)      # bl, br, ur, ul as (y, x)
+        quads[k] = base + [cy, cx] + rng.uniform(-w, w, (4, 2))
+        if k % 5 == 0:
+            quads[k] = np.round(quads[k] * 4) / 4                 # coordinates on a lattice: exact ties happen
+    pts, qq = [], []
+    for k in range(n):
+        q = quads[k]
+        for e in range(4):
+            A, B = q[e], q[(e + 1) % 4]
+            lo, hi = min(A[0], B[0]), max(A[0], B[0])
+            if lo == hi:
+                continue
+            for y in (rng.uniform(lo, hi), hi, _step_ulps(lo, 1), 0.5 * (lo + hi)):
+                X = (y - A[0]) * (B[1] - A[1]) / (B[0] - A[0]) + A[1]        # the reference's expression, same order
+                for ku in (-3, -1, 0, 1, 3):
+                    pts.append((y, _step_ulps(X, ku))); qq.append(k)
+        for vtx in q:                                             # on the vertices and level with them
+            pts.append((vtx[0], vtx[1])); qq.append(k)
+            pts.append((vtx[0], q[:, 1].mean())); qq.append(k)
+    pts = np.array(pts); qq = np.array(qq)
+    got = ctx.eval_inside(pts, quads[qq])                         # raises if the two device forms ever differ
+    ref = np.array([orc.IsInsideQuadrangle(pts[m, 0], pts[m, 1], quads[qq[m]]) for m in range(0, len(pts), 7)])
+    assert np.array_equal(got[::7], ref)
+    assert 0.2 < got.mean() < 0.8
+    # bulk: random points around random cells, device forms against each other (5e6 points)
+    m = 5_000_000
+    qi = rng.integers(0, n, m)
+    c = quads[qi].mean(axis=1)
+    ctx.eval_inside(c + rng.uniform(-8, 8, (m, 2)), quads[qi])
+    # non-finite inputs take the plain path
+    bad = np.array([[np.nan, 0.], [0., np.nan], [np.inf, 0.], [0., -np.inf], [0., np.inf]])
+    assert not ctx.eval_inside(bad + quads[:5].mean(axis=1), quads[:5]).any()
+
+
+def test_euler_update_without_division(ctx):
+    """`r + (vel*rdt)/1000.` through the hot loop's constant division (sitrk_geom.h::div1000): bit-identical to numpy
+    for ordinary speeds, signed zeros, subnormals, huge values, inf and NaN."""
+    rng = np.random.default_rng(12)
+    n = 4_000_000
+    vel = rng.standard_normal(n) * 10.0 ** rng.uniform(-12, 4, n)
+    vel[:200000] = rng.standard_normal(200000).astype(np.float32)              # f32 velocities, as on disk
+    special = np.array([0.0, -0.0, 5e-324, -5e-324, 1e-310, 2.0 ** -1022, 2.0 ** -905, 2.0 ** -912, 2.0 ** -911 * 1.7,
+                        2.0 ** 888, 2.0 ** 889, -2.0 ** 1000, 1e300, 1.7e308, np.inf, -np.inf, np.nan, 1e20, 9.96921e36])
+    vel[-special.size:] = special
+    r = rng.uniform(-5000, 5000, n)
+    r[-special.size:] = np.where(np.arange(special.size) % 2, -0.0, 0.0)          # keeps the sign of a zero quotient visible
+    for rdt in (3600., 1.0, 900.):
+        with np.errstate(all="ignore"):
+            want = r + (vel * rdt) / 1000.
+        got = ctx.eval_euler(r, vel, rdt)
+        nan = np.isnan(want)
+        assert np.array_equal(np.isnan(got), nan)
+        assert np.array_equal(got[~nan].view(np.int64), want[~nan].view(np.int64))
+
+
 def test_extra_linear_interpolation_rule():
     """uv_strategy = 2 is not in the reference; the GPU implementation is held against its independent C restatement,
     and it must differ from the two reference rules while staying between the two face values."""
