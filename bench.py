@@ -136,10 +136,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(dev)
+        import datetime
+        tmo = datetime.timedelta(seconds=300)           # a stuck collective ends the run instead of hanging it
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev), timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     red_dev = "cuda" if backend == "nccl" else "cpu"        # where the small reduction tensors live

@@ -158,3 +158,25 @@ def test_slot_tensor_broadcast_world1_rccl():
             assert np.array_equal(outs[0][key], outs[1][key])
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_as_the_driver_launches_it():
+    """bench.py under `python -m torch.distributed.run --nproc-per-node 2` (the driver's launch line), both ranks on the
+    box's one GPU with gloo as transport (RCCL refuses two ranks per device): one JSON line from rank 0, whole-job value."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SITRK_DIST_BACKEND="gloo", SITRK_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "40", "--warmup", "8", "--config", "c2",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 40 and d["warmup"] == 8 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["buoys_per_gpu"] == 100000 and "broadcast from rank 0" in d["config"]["records_via"]
+    assert abs(d["value"] - 2 * 100000 * 40 / (d["ms_per_step"] * 40e-3)) < 1e-6 * d["value"]
