@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--buoys", type=int, default=0, help="override the configuration's buoys per GPU (capacity runs; not the metric's workload)")
     ap.add_argument("--records", type=int, default=8, help="device-resident records cycled")
     ap.add_argument("--resort", type=int, default=-1, help="re-sort buoys by cell every R steps (0 never, -1 default)")
     ap.add_argument("--uv-strategy", type=int, default=1)
@@ -147,6 +148,9 @@ def main():
     red_dev = "cuda" if backend == "nccl" else "cpu"        # where the small reduction tensors live
 
     Nj, Ni, nP, label = CONFIGS[a.config]
+    if a.buoys > 0:
+        nP = a.buoys
+        label += " [--buoys %d override]" % nP
     K = a.records
     grid = syn.make_grid(Nj, Ni, dkm=4.0, warp=0.0)
     # buoys: rank r owns the r-th contiguous range of the world*nP set
@@ -324,7 +328,7 @@ def main():
         traffic = traffic_fused = None
         prof_fused = {}
         tj = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tj):
+        if os.path.exists(tj) and a.buoys == 0:        # the profiled counters belong to the configuration's own size
             try:
                 tjd = json.load(open(tj))
                 traffic = tjd.get(a.config, {}).get("hbm_bytes_per_launch")
