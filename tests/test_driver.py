@@ -114,10 +114,9 @@ def _write_nc3(fname, dims, variables, attrs=None):
     f.close()
 
 
-def make_case(tmp, nrec=14, nP=300, two_d_time=False):
+def make_case(tmp, nrec=14, nP=300, two_d_time=False, Nj=60, Ni=70, dkm=10.0):
     """Synthetic NANUK-like inputs as NetCDF-3 files: mesh_mask, icemod (hourly), seeding file."""
     from oracle import oracle as orc
-    Nj, Ni, dkm = 60, 70, 10.0
     g = syn.make_grid(Nj, Ni, dkm=dkm, warp=1.0)
     for k in ("Yt", "Yu", "Yv", "Yf"):
         g[k] = g[k] - 250.
@@ -164,10 +163,10 @@ def make_case(tmp, nrec=14, nP=300, two_d_time=False):
             sv[k] = (sv[k][0], sv[k][1], np.repeat(sv[k][2], 2, axis=0), None)
         sv["time_pos"] = ('i4', ('time', 'buoy'), tp, {"units": ncio.tunits_default})
     _write_nc3(seed, {"time": None, "buoy": nP}, sv)
-    return dict(g=g, ll=ll, tmask=tmask, u=u, v=v, sic=sic, tc=tc, yx=yx, sll=sll, ids=ids, mm=mm, si3=si3, seed=seed, base=base)
+    return dict(g=g, ll=ll, tmask=tmask, u=u, v=v, sic=sic, tc=tc, yx=yx, sll=sll, ids=ids, mm=mm, si3=si3, seed=seed, base=base, dkm=dkm)
 
 
-def oracle_run(c, two_d_time, rdt=3600.):
+def oracle_run(c, two_d_time, rdt=3600., nthreads=1):
     """Independent restatement of the whole driver with the CPU oracle (same file contents)."""
     from oracle import oracle as orc
     g = c["g"]
@@ -181,11 +180,12 @@ def oracle_run(c, two_d_time, rdt=3600.):
     latT = c["ll"]["t"][:, 0].reshape(Nj, Ni); lonT = np.mod(c["ll"]["t"][:, 1], 360.).reshape(Nj, Ni)
     pSG = np.stack([c["sll"][:, 0].astype('f4').astype('f8'), np.mod(c["sll"][:, 1].astype('f4').astype('f8'), 360.)], axis=1)
     pSC = c["yx"].astype('f4').astype('f8')
-    res = np.full((Nj, Ni), np.sqrt(2.) * 10.0)
+    res = np.full((Nj, Ni), np.sqrt(2.) * c.get("dkm", 10.0))
     tc = c["tc"]
     kstrt, Nt = 0, len(tc)
     nP, oSG, oSC, oIDs, ojiT, overt, keep = orc.SeedInit(c["ids"], pSG, pSC, np.ascontiguousarray(latT), np.ascontiguousarray(lonT),
-                                                          grid["Yf"], grid["Xf"], res, c["tmask"], c["sic"][kstrt].astype('f8'))
+                                                          grid["Yf"], grid["Xf"], res, c["tmask"], c["sic"][kstrt].astype('f8'),
+                                                          nthreads=nthreads)
     z1 = np.zeros(nP, dtype=int) + kstrt; zL = np.zeros(nP, dtype=int) + (kstrt + Nt - 1)
     if two_d_time:
         base = c["base"]
@@ -193,7 +193,7 @@ def oracle_run(c, two_d_time, rdt=3600.):
         tp1 = np.full(len(c["ids"]), tc[-1] + 1800); tp1[::5] = base + 9 * 3600
         z1, zL = drv.record_windows(np.stack([tp0, tp1]), tc, kstrt, kstrt + Nt - 1, tc[0], tc[-1], len(c["ids"]))
         z1, zL = z1[keep], zL[keep]
-    trk = orc.Tracker(grid, oSC, ojiT, rec_first=z1, rec_last=zL)
+    trk = orc.Tracker(grid, oSC, ojiT, rec_first=z1, rec_last=zL, nthreads=nthreads)
     pos = np.zeros((Nt + 1, nP, 2)) + -9999.; msk = np.zeros((Nt + 1, nP), dtype='i1')
     pos[z1 - kstrt, np.arange(nP)] = oSC; msk[z1 - kstrt, np.arange(nP)] = 1
     for jt in range(Nt):
