@@ -104,7 +104,7 @@ __global__ __launch_bounds__(kBlock) void buoy_rows_kernel(int64_t n, const int3
 
 __device__ __forceinline__ pt load_f(const CellGeo *__restrict__ geo, int j, int i, int Nj, int Ni)
 {
-    return geo[(size_t)pywrap(j, Nj) * Ni + pywrap(i, Ni)].f;
+    return geo[(unsigned)(pywrap(j, Nj) * Ni + pywrap(i, Ni))].f;          // Nj*Ni < 2^31 (sitrk_set_grid)
 }
 
 // CrossedEdge + NewHostCell + UpdtInd4NewCell + Survive   reference sitrack/tracking.py:62-93,182-305
@@ -133,19 +133,26 @@ __device__ __forceinline__ int32_t resolve_crossing(pt P1, pt P2, pt bl, pt br, 
     //   4   ul -> F[jT  ,iT-2]  => 8 (+1,-1)                bl -> F[jT-1,iT-2]  => 5 (-1,-1)           ( 0,-1)
     const pt va = (kc == 1) ? bl : (kc == 2) ? br : ul;
     const pt vb = (kc == 1) ? br : (kc == 4) ? bl : ur;
-    const int jA = (kc == 1) ? jT - 2 : (kc == 2) ? jT - 1 : (kc == 3) ? jT + 1 : jT;
-    const int iA = (kc == 1) ? iT - 1 : (kc == 2) ? iT + 1 : (kc == 3) ? iT - 1 : iT - 2;
-    const int jB = (kc == 1) ? jT - 2 : (kc == 2) ? jT : (kc == 3) ? jT + 1 : jT - 1;
-    const int iB = (kc == 1) ? iT : (kc == 2) ? iT + 1 : (kc == 3) ? iT : iT - 2;
-    const int djS = (kc == 1) ? -1 : (kc == 3) ? 1 : 0, diS = (kc == 2) ? 1 : (kc == 4) ? -1 : 0;
-    const int djA = (kc <= 2) ? -1 : 1, diA = (kc == 2) ? 1 : -1;          // codes 5,6,8,8
-    const int djB = (kc == 1 || kc == 4) ? -1 : 1, diB = (kc == 4) ? -1 : 1;   // codes 6,7,7,5
-    // one batch of independent loads
+    // the ten index offsets of the table above come out of 2-bit lookup words (entry kc-1 holds offset+2): one
+    // bit-field extract each instead of a chain of selects -- the crossing path runs in every wave on every record
+    // with a few lanes active, so its instruction count is paid in full
+#define SITRK_TAB4(e1, e2, e3, e4) ((unsigned)(((e1) + 2) | (((e2) + 2) << 2) | (((e3) + 2) << 4) | (((e4) + 2) << 6)))
+#define SITRK_LOOKUP(word) ((int)(((word) >> sh) & 3u) - 2)
+    const unsigned sh = 2u * (unsigned)(kc - 1);
+    const int jA = jT + SITRK_LOOKUP(SITRK_TAB4(-2, -1, 1, 0)), iA = iT + SITRK_LOOKUP(SITRK_TAB4(-1, 1, -1, -2));
+    const int jB = jT + SITRK_LOOKUP(SITRK_TAB4(-2, 0, 1, -1)), iB = iT + SITRK_LOOKUP(SITRK_TAB4(0, 1, 0, -2));
+    const int djS = SITRK_LOOKUP(SITRK_TAB4(-1, 0, 1, 0)), diS = SITRK_LOOKUP(SITRK_TAB4(0, 1, 0, -1));
+    const int djA = SITRK_LOOKUP(SITRK_TAB4(-1, -1, 1, 1)), diA = SITRK_LOOKUP(SITRK_TAB4(-1, 1, -1, -1));      // codes 5,6,8,8
+    const int djB = SITRK_LOOKUP(SITRK_TAB4(-1, 1, 1, -1)), diB = SITRK_LOOKUP(SITRK_TAB4(1, 1, 1, -1));        // codes 6,7,7,5
+#undef SITRK_LOOKUP
+#undef SITRK_TAB4
+    // one batch of independent loads (only the extension points can index below zero, and then numpy wraps)
     const pt eA = load_f(geo, jA, iA, Nj, Ni);
     const pt eB = load_f(geo, jB, iB, Nj, Ni);
-    const int8_t kS = kill[(size_t)(jT + djS) * Ni + (iT + diS)];
-    const int8_t kA = kill[(size_t)(jT + djA) * Ni + (iT + diA)];
-    const int8_t kB = kill[(size_t)(jT + djB) * Ni + (iT + diB)];
+    const int kT = jT * Ni + iT;                                            // < 2^31 (sitrk_set_grid)
+    const int8_t kS = kill[(unsigned)(kT + djS * Ni + diS)];
+    const int8_t kA = kill[(unsigned)(kT + djA * Ni + diA)];
+    const int8_t kB = kill[(unsigned)(kT + djB * Ni + diB)];
     const bool sva = (kc == 1) ? sbl : (kc == 2) ? sbr : sul;               // ccw(P1,P2,va), already known
     const bool svb = (kc == 1) ? sbr : (kc == 4) ? sbl : sur;
     const bool hitA = (ccw(P1, va, eA) != ccw(P2, va, eA)) && (sva != ccw(P1, P2, eA));
