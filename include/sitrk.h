@@ -62,7 +62,7 @@ int         sitrk_set_stream(sitrk_t *h, void *hip_stream);
  * The arrays GetModelGrid / GetModelUVGrid hand to the loop
  * (sitrack/ncio.py:22-92; si3_part_tracker.py:192,196): F-, U-, V-point plane
  * coordinates [km] and the T-point land-sea mask.  Copied to the device once and
- * re-laid out as one 48-byte record per cell.  4 <= Nj <= 32767, 4 <= Ni <= 65535. */
+ * re-laid out as one 48-byte record per cell.  4 <= Nj <= 32767, 4 <= Ni <= 65535, Nj*Ni <= 2^29. */
 int sitrk_set_grid(sitrk_t *h, int Nj, int Ni,
                    const double *Yf, const double *Xf,
                    const double *Yu, const double *Xu,

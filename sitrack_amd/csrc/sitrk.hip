@@ -150,6 +150,8 @@ SITRK_API int sitrk_set_grid(sitrk_t *h, int Nj, int Ni, const double *Yf, const
     NEED(Yf && Xf && Yu && Xu && Yv && Xv && tmask, "sitrk_set_grid: null array");
     if (Nj < 4 || Nj > 32767 || Ni < 4 || Ni > 65535)
         return fail(h, SITRK_EINVAL, "sitrk_set_grid: grid %dx%d outside 4..32767 x 4..65535", Nj, Ni);
+    if ((int64_t)Nj * Ni > ((int64_t)1 << 29))      // byte offsets inside one fp64 field stay below 2^32 (CellCtx)
+        return fail(h, SITRK_EINVAL, "sitrk_set_grid: grid %dx%d has more than 2^29 cells", Nj, Ni);
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     dev_free(h->geo); dev_free(h->tmask); dev_free(h->slabs); dev_free(h->kill);

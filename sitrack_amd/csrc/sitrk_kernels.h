@@ -333,20 +333,24 @@ struct RunArgs {
 // measured 7 % slower: more instructions in an issue-bound loop).
 // ---------------------------------------------------------------------------
 struct CellCtx {
-    size_t k;
+    unsigned o1, o0;                    // byte offsets of cell (jT,iT) and of (jT-1,iT) inside a field of the record
+                                        // (32 bits: sitrk_set_grid keeps Nj*Ni*8 below 2^32) -> a record's velocities are
+                                        // loaded as (scalar record pointer + this offset), no address arithmetic per record
     pt F11, U11, V11, F10, U10, F01, V01, F00;
     bool sFV, sFU;                      // ccw(F11,V01,V11), ccw(F11,U10,U11)
 };
 
+template <unsigned ES>
 __device__ __forceinline__ void load_ctx(const StepArgs &a, int32_t c, CellCtx &x)
 {
     const int Ni = a.Ni;
-    x.k = (size_t)cell_j(c) * Ni + cell_i(c);
-    const CellGeo g11 = a.geo[x.k];
+    const unsigned k = (unsigned)(cell_j(c) * Ni + cell_i(c));
+    x.o1 = k * ES; x.o0 = (k - (unsigned)Ni) * ES;
+    const CellGeo g11 = a.geo[k];
     x.F11 = g11.f; x.U11 = g11.u; x.V11 = g11.v;
-    x.F10 = a.geo[x.k - 1].f; x.U10 = a.geo[x.k - 1].u;
-    x.F01 = a.geo[x.k - Ni].f; x.V01 = a.geo[x.k - Ni].v;
-    x.F00 = a.geo[x.k - Ni - 1].f;
+    x.F10 = a.geo[k - 1].f; x.U10 = a.geo[k - 1].u;
+    x.F01 = a.geo[k - Ni].f; x.V01 = a.geo[k - Ni].v;
+    x.F00 = a.geo[k - Ni - 1].f;
     x.sFV = ccw(x.F11, x.V01, x.V11);
     x.sFU = ccw(x.F11, x.U10, x.U11);
 }
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(kBlock, 5) void advect_run_kernel(RunArgs ra)
     const int Ni = a.Ni, Nj = a.Nj;
     bool moved = false;
     CellCtx x;
-    load_ctx(a, c, x);
+    load_ctx<sizeof(FT)>(a, c, x);
 #pragma unroll 1
     for (int r = 0; r < ra.nrec; r++) {
         const int jrec = a.jrec + r;
@@ -376,19 +380,19 @@ __global__ __launch_bounds__(kBlock, 5) void advect_run_kernel(RunArgs ra)
             if (jrec < first) continue;
             if (jrec > last) break;
         }
-        const FT *__restrict__ u = (const FT *)ra.u[r];
-        const FT *__restrict__ v = (const FT *)ra.v[r];
+        // the four velocity candidates u[jT,iT-1], u[jT,iT], v[jT-1,iT], v[jT,iT]
+        const char *ub = (const char *)ra.u[r], *vb = (const char *)ra.v[r];
+        FT fu0 = *(const FT *)(ub + x.o1 - sizeof(FT)), fu1 = *(const FT *)(ub + x.o1);
+        FT fv0 = *(const FT *)(vb + x.o0), fv1 = *(const FT *)(vb + x.o1);
         double zU, zV;
         if (UVS == 0) {                                  // :423-425
-            zU = 0.5 * ((double)u[x.k] + (double)u[x.k - 1]);
-            zV = 0.5 * ((double)v[x.k] + (double)v[x.k - Ni]);
+            zU = 0.5 * ((double)fu1 + (double)fu0);
+            zV = 0.5 * ((double)fv1 + (double)fv0);
         } else if (UVS == 2) {                           // extra: linear interpolation (not in the reference)
-            zU = lerp_on_segment(P, x.U10, x.U11, (double)u[x.k - 1], (double)u[x.k]);
-            zV = lerp_on_segment(P, x.V01, x.V11, (double)v[x.k - Ni], (double)v[x.k]);
+            zU = lerp_on_segment(P, x.U10, x.U11, (double)fu0, (double)fu1);
+            zV = lerp_on_segment(P, x.V01, x.V11, (double)fv0, (double)fv1);
         } else {                                         // :427-441
             // all four candidates are requested up front (pin_load: none is sunk into the branch that selects it)
-            FT fu1 = u[x.k], fu0 = u[x.k - 1];
-            FT fv1 = v[x.k], fv0 = v[x.k - Ni];
             // intersect2Seg(P,F,C,D) = (ccw(P,C,D) != ccw(F,C,D)) and (ccw(P,F,C) != ccw(P,F,D)); ccw(F,C,D) is per cell
             const bool llum1 = (ccw(P, x.V01, x.V11) != x.sFV) && (ccw(P, x.F11, x.V01) != ccw(P, x.F11, x.V11));
             const bool llvm1 = (ccw(P, x.U10, x.U11) != x.sFU) && (ccw(P, x.F11, x.U10) != ccw(P, x.F11, x.U11));
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(kBlock, 5) void advect_run_kernel(RunArgs ra)
         bool killed = false;
         if (!SITRK_INSIDE(Pn.y, Pn.x, x.F00, x.F01, x.F11, x.F10, a.eps_mg)) {      // :466-484
             c = resolve_crossing(P, Pn, x.F00, x.F01, x.F11, x.F10, cell_j(c), cell_i(c), Nj, Ni, a.geo, ra.kill[r], killed);
-            if (!killed) load_ctx(a, c, x);
+            if (!killed) load_ctx<sizeof(FT)>(a, c, x);
         }
         P = Pn;
         if (killed) {

@@ -580,6 +580,13 @@ def test_record_latlon_of_dead_and_live(ctx):
 
 def test_errors(ctx):
     grid = syn.make_grid(16, 16)
+    # size limits are checked before any array is read: 32767 x 65535, and 2^29 cells (32-bit byte offsets in a field)
+    import ctypes as C
+    dummy = (C.c_double * 4)()
+    dm = C.cast(dummy, C.c_void_p)
+    for nj, ni in ((32768, 16), (16, 65536), (3, 16), (32767, 16385), (23171, 23171)):
+        assert ctx._L.sitrk_set_grid(ctx._h, nj, ni, dm, dm, dm, dm, dm, dm, dm) != 0, (nj, ni)
+        assert b"sitrk_set_grid" in ctx._L.sitrk_last_error(ctx._h)
     ctx.set_grid(grid["Yf"], grid["Xf"], grid["Yu"], grid["Xu"], grid["Yv"], grid["Xv"], grid["tmask"])
     with pytest.raises(IndexError):
         ctx.set_buoys(np.zeros((1, 2)), np.array([[0, 5]]))
