@@ -125,22 +125,23 @@ __device__ __forceinline__ bool inside_quad_hot(double y, double x, pt q0, pt q1
     const double mx = __builtin_fma(fabs(x), 0x1p-48, eps_mg);
     const bool g0 = y > q0.y, g1 = y > q1.y, g2 = y > q2.y, g3 = y > q3.y;
     const bool l0 = x <= q0.x, l1 = x <= q1.x, l2 = x <= q2.x, l3 = x <= q3.x;
-    bool inside = false, undecided = false;
+    bool inside = false, decided = true;                 // logical operators: the predicates stay lane masks
 #define SITRK_EDGE(A, B, gA, gB, lA, lB)                                              \
-    if ((gA != gB) & (lA | lB)) {                                                     \
+    if ((gA != gB) && (lA || lB)) {                                                   \
         double c = B.y - A.y;                                                         \
         asm volatile("" : "+v"(c));                                                   \
         const double p = (y - A.y) * (B.x - A.x);                                     \
         const double E = __builtin_fma(x - A.x, c, -p);                               \
         const bool dec = fabs(E) > __builtin_fma(fabs(c), mx, 0x1p-1000);             \
-        undecided |= !dec;                                                            \
-        inside ^= dec & ((__double2hiint(E) < 0) == gA);                              \
+        decided = decided && dec;                                                     \
+        inside = inside != (dec && ((__double2hiint(E) < 0) == gA));                  \
     }
     SITRK_EDGE(q0, q1, g0, g1, l0, l1)
     SITRK_EDGE(q1, q2, g1, g2, l1, l2)
     SITRK_EDGE(q2, q3, g2, g3, l2, l3)
     SITRK_EDGE(q3, q0, g3, g0, l3, l0)
 #undef SITRK_EDGE
+    const bool undecided = !decided;
     if (undecided) inside = inside_quad(y, x, q0, q1, q2, q3);
     return inside;
 }
