@@ -105,7 +105,7 @@ SITRK_API int sitrk_create(sitrk_t **out, int device)
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
         (e = hipMalloc((void **)&c->counter, sizeof(unsigned long long))) != hipSuccess) {
         int rc = fail(h, SITRK_EHIP, "sitrk_create: %s", hipGetErrorString(e));
-        delete c;
+        (void)sitrk_destroy(c);                 // releases whatever was created before the failure
         return rc;
     }
     c->stream = c->own_stream;
@@ -397,7 +397,12 @@ SITRK_API int sitrk_set_buoys(sitrk_t *h, int64_t nP, const double *yx, const in
     h->windowed = (rec_first != nullptr);
     h->cur = 0; h->steps_since_sort = 0; h->sorted_once = false;
     // host-side validation + packing of the host cell
-    std::vector<int32_t> packed((size_t)nP);
+    std::vector<int32_t> packed;
+    try {
+        packed.resize((size_t)nP);
+    } catch (const std::bad_alloc &) {          // no C++ exception may cross the C ABI
+        return fail(h, SITRK_ENOMEM, "sitrk_set_buoys: out of host memory for %lld buoys", (long long)nP);
+    }
     for (int64_t p = 0; p < nP; p++) {
         int j = jiT[2 * p], i = jiT[2 * p + 1];
         if (j < 1 || j > h->Nj - 2 || i < 1 || i > h->Ni - 2)
