@@ -119,7 +119,7 @@ SITRK_API int sitrk_destroy(sitrk_t *h)
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     free_buoys(h);
-    dev_free(h->geo); dev_free(h->tmask); dev_free(h->slabs); dev_free(h->kill); dev_free(h->scratch); dev_free(h->counter);
+    dev_free(h->geo); dev_free(h->orient); dev_free(h->tmask); dev_free(h->slabs); dev_free(h->kill); dev_free(h->scratch); dev_free(h->counter);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -154,11 +154,12 @@ SITRK_API int sitrk_set_grid(sitrk_t *h, int Nj, int Ni, const double *Yf, const
         return fail(h, SITRK_EINVAL, "sitrk_set_grid: grid %dx%d has more than 2^29 cells", Nj, Ni);
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
-    dev_free(h->geo); dev_free(h->tmask); dev_free(h->slabs); dev_free(h->kill);
-    h->geo = nullptr; h->tmask = nullptr; h->slabs = nullptr; h->kill = nullptr; h->nslots = 0;
+    dev_free(h->geo); dev_free(h->orient); dev_free(h->tmask); dev_free(h->slabs); dev_free(h->kill);
+    h->geo = nullptr; h->orient = nullptr; h->tmask = nullptr; h->slabs = nullptr; h->kill = nullptr; h->nslots = 0;
     free_buoys(h);
     const size_t n = (size_t)Nj * Ni;
     HIPCHK(dev_alloc(&h->geo, n));
+    HIPCHK(dev_alloc(&h->orient, n));
     HIPCHK(dev_alloc(&h->tmask, n));
     // stage the six arrays in scratch, interleave on the device
     int rc = ensure_scratch(h, 6 * n * sizeof(double));
@@ -169,6 +170,8 @@ SITRK_API int sitrk_set_grid(sitrk_t *h, int Nj, int Ni, const double *Yf, const
     HIPCHK(hipMemcpyAsync(h->tmask, tmask, n, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(build_geo_kernel, dim3(nblocks((int64_t)n)), dim3(kBlock), 0, h->stream, n, s, s + n, s + 2 * n, s + 3 * n,
                        s + 4 * n, s + 5 * n, h->geo);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(cell_orient_kernel, dim3(nblocks((int64_t)n)), dim3(kBlock), 0, h->stream, Nj, Ni, h->geo, h->orient);
     HIPCHK(hipGetLastError());
     // margin scale of the division-free cell test: every vertex coordinate is <= mg in magnitude
     // (a non-finite vertex makes it inf/NaN: nothing is decided by the filter and the plain test runs)
@@ -535,7 +538,7 @@ SITRK_API int sitrk_step(sitrk_t *h, int slot, int jrec)
     StepArgs a;
     a.nP = h->nP; a.tune = h->tune; a.Nj = h->Nj; a.Ni = h->Ni; a.jrec = jrec;
     a.rdt = h->rdt; a.rmin_conc = h->rmin_conc; a.eps_mg = h->eps_mg;
-    a.geo = h->geo; a.kill = h->kill + (size_t)slot * n;
+    a.geo = h->geo; a.orient = h->orient; a.kill = h->kill + (size_t)slot * n;
     a.u = slab; a.v = slab + n * es;
     a.pos = s.pos; a.cell = s.cell; a.kill_rec = s.kill_rec; a.first = s.first; a.last = s.last;
     if (h->dtype == SITRK_F64) launch_step<double>(h, a);
@@ -594,7 +597,7 @@ SITRK_API int sitrk_run(sitrk_t *h, int slot0, int jrec0, int nsteps)
         BuoyState &s = h->st[h->cur];
         RunArgs ra;
         ra.s.nP = h->nP; ra.s.tune = h->tune; ra.s.Nj = h->Nj; ra.s.Ni = h->Ni; ra.s.jrec = jrec0 + k;
-        ra.s.rdt = h->rdt; ra.s.rmin_conc = h->rmin_conc; ra.s.eps_mg = h->eps_mg; ra.s.geo = h->geo; ra.s.kill = nullptr; ra.s.u = ra.s.v = nullptr;
+        ra.s.rdt = h->rdt; ra.s.rmin_conc = h->rmin_conc; ra.s.eps_mg = h->eps_mg; ra.s.geo = h->geo; ra.s.orient = h->orient; ra.s.kill = nullptr; ra.s.u = ra.s.v = nullptr;
         ra.s.pos = s.pos; ra.s.cell = s.cell; ra.s.kill_rec = s.kill_rec; ra.s.first = s.first; ra.s.last = s.last;
         ra.nrec = m;
         for (int r = 0; r < m; r++) {

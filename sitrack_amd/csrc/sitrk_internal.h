@@ -35,6 +35,7 @@ struct sitrk_ctx {
     // grid
     int Nj = 0, Ni = 0;
     sitrk::CellGeo *geo = nullptr;      // (Nj*Ni) 48-byte records
+    int8_t *orient = nullptr;           // (Nj*Ni) orientation bits of the velocity pick (cell_orient_kernel)
     int8_t *tmask = nullptr;
 
     // parameters

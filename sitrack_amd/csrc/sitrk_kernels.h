@@ -34,6 +34,22 @@ __global__ void build_geo_kernel(size_t n, const double *__restrict__ Yf, const 
     geo[k] = g;
 }
 
+// The two orientation terms of the velocity pick (:427-441) that do not depend on the buoy,
+//   ccw(F[j,i], V[j-1,i], V[j,i])  (bit 0)   and   ccw(F[j,i], U[j,i-1], U[j,i])  (bit 1),
+// once per cell: the fused kernel reads one byte when a buoy enters a cell instead of evaluating them.
+__global__ void cell_orient_kernel(int Nj, int Ni, const CellGeo *__restrict__ geo, int8_t *__restrict__ orient)
+{
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (size_t)Nj * Ni) return;
+    const int j = (int)(k / Ni), i = (int)(k % Ni);
+    int8_t o = 0;
+    if (j >= 1 && i >= 1) {
+        const CellGeo g = geo[k];
+        o = (ccw(g.f, geo[k - Ni].v, g.v) ? 1 : 0) | (ccw(g.f, geo[k - 1].u, g.u) ? 2 : 0);
+    }
+    orient[k] = o;
+}
+
 // ---------------------------------------------------------------------------
 // Survive   reference sitrack/tracking.py:62-93   (returns true = kill)
 // ---------------------------------------------------------------------------
@@ -218,6 +234,7 @@ struct StepArgs {
     double rdt, rmin_conc;
     double eps_mg;                      // 2^-48 * max |F-point coordinate| : margin scale of inside_quad_hot
     const CellGeo *geo;
+    const int8_t *orient;               // per-cell orientation bits (cell_orient_kernel)
     const int8_t *kill;                 // the record's Survive mask (survive_mask_kernel)
     const void *u, *v;
     pt *pos;
@@ -351,8 +368,9 @@ __device__ __forceinline__ void load_ctx(const StepArgs &a, int32_t c, CellCtx &
     x.F10 = a.geo[k - 1].f; x.U10 = a.geo[k - 1].u;
     x.F01 = a.geo[k - Ni].f; x.V01 = a.geo[k - Ni].v;
     x.F00 = a.geo[k - Ni - 1].f;
-    x.sFV = ccw(x.F11, x.V01, x.V11);
-    x.sFU = ccw(x.F11, x.U10, x.U11);
+    const int8_t ori = a.orient[k];
+    x.sFV = (ori & 1) != 0;             // ccw(F11, V01, V11)
+    x.sFU = (ori & 2) != 0;             // ccw(F11, U10, U11)
 }
 
 template <typename FT, int UVS, bool WINDOW>
