@@ -6,4 +6,6 @@ names (`sit.SeedInit`, `sit.CartNPSkm2Geo1D`, `sit.GetTimeSpan`, ...).
 from ._lib import Context, SitrkError, FillValue, build, lib, SO_PATH      # noqa: F401
 from .tracking import (SeedInit, FindContainingCell, CartNPSkm2Geo1D, Geo2CartNPSkm1D, GetTimeSpan,  # noqa: F401
                        IceTracker, vertices_of, default_context, rmin_conc, rFoundKM)
+from .predicates import (_ccw_, intersect2Seg, IsInsideQuadrangle, CrossedEdge, NewHostCell, UpdtInd4NewCell,  # noqa: F401
+                         Survive)
 from . import synthetic                                                      # noqa: F401

@@ -1,0 +1,67 @@
+"""The reference's scalar predicates under their own names (sitrack_amd/predicates.py), called the way the reference's
+loop body and its own test call them, against the golden vectors produced by the reference functions themselves."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sit():
+    import sitrack_amd
+    return sitrack_amd
+
+
+def test_pnt_inside_quad_like_the_reference_test(sit):
+    # reference tools/tests/test_pnt_inside_quad.py:16-24
+    quad = np.array([[0., 0.], [3., 0.], [4., 4.], [1., 3.5]])
+    got = [sit.IsInsideQuadrangle(y, x, quad) for (y, x) in ((2., 2.), (6., 6.), (-1., 2.), (3.1, 3.6))]
+    assert got == [True, False, False, True]
+
+
+def test_inside_and_intersect_scalars(sit, golden):
+    g1, g2 = golden("g1_inside.npz"), golden("g2_intersect.npz")
+    for k in range(0, len(g1["pts"]), 40):
+        assert sit.IsInsideQuadrangle(g1["pts"][k, 0], g1["pts"][k, 1], g1["quads"][k]) == bool(g1["inside"][k])
+    for k in range(0, len(g2["P"]), 70):
+        A, B, Cc, D = g2["P"][k]
+        assert sit.intersect2Seg(A, B, Cc, D) == bool(g2["intersect"][k])
+        assert sit._ccw_(A, B, Cc) == bool(g2["ccw"][k])
+
+
+def test_crossing_chain_like_the_loop_body(sit, golden):
+    """si3_part_tracker.py:474-480: icross = CrossedEdge(...); inhc = NewHostCell(icross, ...); UpdtInd4NewCell(inhc, ...)"""
+    g = golden("g3_crossing.npz")
+    Yf, Xf = g["Yf"], g["Xf"]
+    seen = set()
+    for k in range(0, len(g["P1"]), 6):
+        vert = g["vert"][k].copy()
+        jiT = g["jiT"][k].copy()
+        icross = sit.CrossedEdge(g["P1"][k], g["P2"][k], vert, Yf, Xf)
+        inhc = sit.NewHostCell(icross, g["P1"][k], g["P2"][k], vert, Yf, Xf)
+        assert (icross, inhc) == (int(g["icross"][k]), int(g["inhc"][k])), k
+        v2, j2 = sit.UpdtInd4NewCell(inhc, vert, jiT)
+        assert v2 is vert and j2 is jiT                                  # in place, like the reference
+        assert np.array_equal(vert, g["vert_out"][k]) and np.array_equal(jiT, g["jiT_out"][k])
+        seen.add(inhc)
+    assert seen == set(range(1, 9))
+    with pytest.raises(SystemExit):
+        sit.UpdtInd4NewCell(9, g["vert"][0].copy(), g["jiT"][0].copy())
+
+
+def test_survive_scalar(sit, golden, capsys):
+    g = golden("g4_survive.npz")
+    for k in range(0, len(g["jiT"]), 3):
+        assert sit.Survive(k, g["jiT"][k], g["tmask"], g["sic"]) == int(g["kill_a"][k]), g["jiT"][k]
+    assert set(np.unique(g["kill_a"])) == {0, 1}
+    # float32 ice field, as read from an SI3 file
+    for k in range(1, len(g["jiT"]), 17):
+        assert sit.Survive(k, g["jiT"][k], g["tmask"], g["sic32"]) == int(g["kill_b"][k])
+    # no 2-D ice field: the rim and the mask still kill; a buoy that passes them trips the reference's own failure
+    alive = np.flatnonzero(g["kill_a"] == 0)[0]
+    with pytest.raises(UnboundLocalError):
+        sit.Survive(7, g["jiT"][alive], g["tmask"])
+    assert sit.Survive(7, [0, 5], g["tmask"]) == 1
+    assert sit.Survive(7, [0, 5], g["tmask"], iverbose=1) == 1 and "CANCEL buoy 7" in capsys.readouterr().out
+    with pytest.raises(IndexError):
+        sit.Survive(7, [g["tmask"].shape[0], 5], g["tmask"], g["sic"])
