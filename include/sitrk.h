@@ -170,6 +170,14 @@ int sitrk_seed_init(sitrk_t *h, int64_t nP, const double *latlon, const double *
                     const double *latT, const double *lonT, const double *resolkm,
                     const double *sic, int32_t *jiT_out, int8_t *keep, int8_t *why);
 
+/* NearestPoint alone (sitrack/locate.py:222-276, whole-domain form with find_ji_of_min :13-20 and Haversine
+ * util.py:85-103): for each of nP points latlon (nP,2) [lat,lon] the (j,i) of the nearest T-point of the current grid's
+ * latT/lonT (Nj,Ni), or (-1,-1) when the acceptance loop gives up (distance >= 0.5*resolkm[j,i] * 1.2^(max_itr-2), or
+ * rd_found_km * 1.2^(max_itr-2) when resolkm is NULL).  SeedInit calls it with rd_found_km = 2.5, max_itr = 10.
+ * dmin (nP) may be NULL: Haversine distance to that T-point in km (+inf for points rejected without a search). */
+int sitrk_nearest_point(sitrk_t *h, int64_t nP, const double *latlon, const double *latT, const double *lonT,
+                        const double *resolkm, double rd_found_km, int max_itr, int32_t *ji, double *dmin);
+
 /* ---- predicate probes ------------------------------------------------------
  * The device-side predicates of the hot path evaluated on plain arrays, so that each one can be held
  * against the reference function it restates (parity tests):
@@ -184,6 +192,9 @@ int sitrk_seed_init(sitrk_t *h, int64_t nP, const double *latlon, const double *
  *                        ice concentration and the current rmin_conc: 1 = kill */
 int sitrk_eval_inside(sitrk_t *h, int64_t n, const double *pts, const double *quads, int8_t *inside);
 int sitrk_eval_euler(sitrk_t *h, int64_t n, const double *r, const double *vel, double rdt, double *out);
+/* Haversine (sitrack/util.py:85-103, R = 6360 km) element by element: dist[k] between (plat[k],plon[k]) and (xlat[k],xlon[k]) */
+int sitrk_eval_haversine(sitrk_t *h, int64_t n, const double *plat, const double *plon, const double *xlat,
+                         const double *xlon, double *dist);
 int sitrk_eval_intersect(sitrk_t *h, int64_t n, const double *segs, int8_t *intersect, int8_t *ccw_abc);
 int sitrk_eval_crossing(sitrk_t *h, int64_t n, const double *P1, const double *P2, const int32_t *jiT, int32_t *jiT_new,
                         int32_t *codes);

@@ -7,5 +7,5 @@ from ._lib import Context, SitrkError, FillValue, build, lib, SO_PATH      # noq
 from .tracking import (SeedInit, FindContainingCell, CartNPSkm2Geo1D, Geo2CartNPSkm1D, GetTimeSpan,  # noqa: F401
                        IceTracker, vertices_of, default_context, rmin_conc, rFoundKM)
 from .predicates import (_ccw_, intersect2Seg, IsInsideQuadrangle, CrossedEdge, NewHostCell, UpdtInd4NewCell,  # noqa: F401
-                         Survive)
+                         Survive, Haversine, NearestPoint)
 from . import synthetic                                                      # noqa: F401

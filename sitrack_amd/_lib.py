@@ -51,6 +51,8 @@ _SIGNATURES = {
     "sitrk_count_alive": (_int, [_vp, C.POINTER(_i64)]),
     "sitrk_find_cells": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "sitrk_seed_init": (_int, [_vp, _i64] + [_vp] * 9),
+    "sitrk_nearest_point": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _dbl, _int, _vp, _vp]),
+    "sitrk_eval_haversine": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "sitrk_eval_inside": (_int, [_vp, _i64, _vp, _vp, _vp]),
     "sitrk_eval_euler": (_int, [_vp, _i64, _vp, _vp, _dbl, _vp]),
     "sitrk_eval_intersect": (_int, [_vp, _i64, _vp, _vp, _vp]),
@@ -315,6 +317,26 @@ class Context:
         self._chk(self._L.sitrk_seed_init(self._h, nP, _ptr(latlon), _ptr(yx), _ptr(latT), _ptr(lonT), _ptr(res), _ptr(sic),
                                           _ptr(jiT), _ptr(keep), _ptr(why)))
         return jiT, keep, why
+
+    def nearest_point(self, latlon, latT, lonT, resolkm=None, rd_found_km=10., max_itr=5):
+        """NearestPoint of the reference for an array of points: (ji (n,2) int32 with -1,-1 = not found, dmin km)."""
+        latlon = as_c(latlon, np.float64)
+        n = latlon.shape[0]
+        latlon = as_c(latlon, np.float64, (n, 2), "latlon")
+        latT = as_c(latT, np.float64, (self.Nj, self.Ni), "latT")
+        lonT = as_c(lonT, np.float64, (self.Nj, self.Ni), "lonT")
+        res = None if resolkm is None else as_c(resolkm, np.float64, (self.Nj, self.Ni), "resolkm")
+        ji = np.empty((n, 2), dtype=np.int32)
+        dmin = np.empty(n, dtype=np.float64)
+        self._chk(self._L.sitrk_nearest_point(self._h, n, _ptr(latlon), _ptr(latT), _ptr(lonT), _ptr(res), float(rd_found_km),
+                                              int(max_itr), _ptr(ji), _ptr(dmin)))
+        return ji, dmin
+
+    def eval_haversine(self, plat, plon, xlat, xlon):
+        plat, plon, xlat, xlon = (np.ascontiguousarray(a, dtype=np.float64) for a in np.broadcast_arrays(plat, plon, xlat, xlon))
+        out = np.empty(plat.shape, dtype=np.float64)
+        self._chk(self._L.sitrk_eval_haversine(self._h, plat.size, _ptr(plat), _ptr(plon), _ptr(xlat), _ptr(xlon), _ptr(out)))
+        return out
 
     # -- predicate probes (parity tests)
     def eval_inside(self, pts, quads):

@@ -738,6 +738,49 @@ SITRK_API int sitrk_find_cells(sitrk_t *h, int64_t n, const double *yx, const in
     return SITRK_OK;
 }
 
+// Nearest T-point of nP seeds by exact branch-and-bound over bounding spheres of the mesh (sitrk_locate.h):
+// kernels are enqueued on h->stream; *kb / *db (flat index, Haversine distance) live in the work buffer *w, which the
+// caller frees after synchronising.  Seeds farther than anything NearestPoint's acceptance loop can accept get
+// kb = 0xffffffff without a search.
+static int nearest_search(sitrk_ctx *h, int64_t nP, const ll *d_ll, const double *d_lat, const double *d_lon, const double *resolkm_host,
+                          double rd_found_km, int max_itr, char **w_out, uint32_t **kb_out, double **db_out)
+{
+    const size_t n = (size_t)h->Nj * h->Ni;
+    const int nbj = (h->Nj + kLB - 1) / kLB, nbi = (h->Ni + kLB - 1) / kLB, sbf = 16;
+    const int nsj = (nbj + sbf - 1) / sbf, nsi = (nbi + sbf - 1) / sbf;
+    const size_t b_u = align256(n * 8), b_blk = align256((size_t)nbj * nbi * sizeof(Sphere)),
+                 b_sb = align256((size_t)nsj * nsi * sizeof(Sphere)), b_kb = align256((size_t)nP * 4), b_db = align256((size_t)nP * 8);
+    char *w = nullptr;
+    HIPCHK(hipMalloc((void **)&w, 3 * b_u + b_blk + b_sb + b_kb + b_db));
+    double *ux = (double *)w, *uy = (double *)(w + b_u), *uz = (double *)(w + 2 * b_u);
+    Sphere *blk = (Sphere *)(w + 3 * b_u), *sblk = (Sphere *)(w + 3 * b_u + b_blk);
+    uint32_t *kb = (uint32_t *)(w + 3 * b_u + b_blk + b_sb);
+    double *db = (double *)(w + 3 * b_u + b_blk + b_sb + b_kb);
+    hipLaunchKernelGGL(unitvec_kernel, dim3(nblocks((int64_t)n)), dim3(kBlock), 0, h->stream, n, d_lat, d_lon, ux, uy, uz);
+    hipLaunchKernelGGL(block_sphere_kernel, dim3((unsigned)(nbj * nbi)), dim3(kBlock), 0, h->stream, h->Nj, h->Ni, nbi, ux, uy, uz, blk);
+    hipLaunchKernelGGL(superblock_sphere_kernel, dim3((unsigned)(nsj * nsi)), dim3(kBlock), 0, h->stream, nbj, nbi, sbf, nsi, blk, sblk);
+    SearchArgs sa;
+    sa.nP = nP; sa.Nj = h->Nj; sa.Ni = h->Ni; sa.nbj = nbj; sa.nbi = nbi; sa.sbf = sbf; sa.nsj = nsj; sa.nsi = nsi;
+    sa.latlon = d_ll; sa.ux = ux; sa.uy = uy; sa.uz = uz; sa.blk = blk; sa.sblk = sblk; sa.latT = d_lat; sa.lonT = d_lon;
+    sa.kbest = kb; sa.dbest = db;
+    {
+        // largest distance the acceptance loop of NearestPoint can ever accept (locate.py:253-266):
+        // rfnd starts at 0.5*resol (or rd_found_km) and is multiplied by 1.2 at most max_itr-2 times
+        double rmax = rd_found_km;
+        if (resolkm_host) {
+            rmax = 0.0;
+            for (size_t c = 0; c < n; c++) rmax = std::max(rmax, 0.5 * resolkm_host[c]);
+        }
+        const double dmax = rmax * std::pow(1.2, std::max(0, max_itr - 2)) * 1.02;   // km on the R = 6360 km Haversine sphere, +2 %
+        const double half = std::min(dmax / (2.0 * 6360.0), M_PI_2);
+        const double chord = 2.0 * std::sin(half);
+        sa.far2 = (std::isfinite(dmax) && dmax >= 0.0) ? chord * chord : __builtin_inf();
+    }
+    hipLaunchKernelGGL(seed_search_kernel, dim3(nblocks(nP, kBlock / 64)), dim3(kBlock), 0, h->stream, sa);
+    *w_out = w; *kb_out = kb; *db_out = db;
+    return SITRK_OK;
+}
+
 SITRK_API int sitrk_seed_init(sitrk_t *h, int64_t nP, const double *latlon, const double *yx, const double *latT,
                               const double *lonT, const double *resolkm, const double *sic, int32_t *jiT_out, int8_t *keep,
                               int8_t *why)
@@ -776,37 +819,11 @@ SITRK_API int sitrk_seed_init(sitrk_t *h, int64_t nP, const double *latlon, cons
         HIPCHK(hipGetLastError());
     } else {
         // exact branch-and-bound over bounding spheres of the mesh (sitrk_locate.h)
-        const int nbj = (h->Nj + kLB - 1) / kLB, nbi = (h->Ni + kLB - 1) / kLB, sbf = 16;
-        const int nsj = (nbj + sbf - 1) / sbf, nsi = (nbi + sbf - 1) / sbf;
-        const size_t b_u = align256(n * 8), b_blk = align256((size_t)nbj * nbi * sizeof(Sphere)),
-                     b_sb = align256((size_t)nsj * nsi * sizeof(Sphere)), b_kb = align256((size_t)nP * 4), b_db = align256((size_t)nP * 8);
         char *w = nullptr;
-        HIPCHK(hipMalloc((void **)&w, 3 * b_u + b_blk + b_sb + b_kb + b_db));
-        double *ux = (double *)w, *uy = (double *)(w + b_u), *uz = (double *)(w + 2 * b_u);
-        Sphere *blk = (Sphere *)(w + 3 * b_u), *sblk = (Sphere *)(w + 3 * b_u + b_blk);
-        uint32_t *kb = (uint32_t *)(w + 3 * b_u + b_blk + b_sb);
-        double *db = (double *)(w + 3 * b_u + b_blk + b_sb + b_kb);
-        hipLaunchKernelGGL(unitvec_kernel, dim3(nblocks((int64_t)n)), dim3(kBlock), 0, h->stream, n, d_lat, d_lon, ux, uy, uz);
-        hipLaunchKernelGGL(block_sphere_kernel, dim3((unsigned)(nbj * nbi)), dim3(kBlock), 0, h->stream, h->Nj, h->Ni, nbi, ux, uy, uz, blk);
-        hipLaunchKernelGGL(superblock_sphere_kernel, dim3((unsigned)(nsj * nsi)), dim3(kBlock), 0, h->stream, nbj, nbi, sbf, nsi, blk, sblk);
-        SearchArgs sa;
-        sa.nP = nP; sa.Nj = h->Nj; sa.Ni = h->Ni; sa.nbj = nbj; sa.nbi = nbi; sa.sbf = sbf; sa.nsj = nsj; sa.nsi = nsi;
-        sa.latlon = d_ll; sa.ux = ux; sa.uy = uy; sa.uz = uz; sa.blk = blk; sa.sblk = sblk; sa.latT = d_lat; sa.lonT = d_lon;
-        sa.kbest = kb; sa.dbest = db;
-        {
-            // largest distance the acceptance loop of NearestPoint can ever accept (locate.py:253-266 with max_itr = 10):
-            // rfnd starts at 0.5*resol (or rd_found_km) and is multiplied by 1.2 at most max_itr-2 times
-            double rmax = 2.5;
-            if (resolkm) {
-                rmax = 0.0;
-                for (size_t c = 0; c < n; c++) rmax = std::max(rmax, 0.5 * resolkm[c]);
-            }
-            const double dmax = rmax * std::pow(1.2, 8) * 1.02;              // km on the R = 6360 km Haversine sphere, +2 %
-            const double half = std::min(dmax / (2.0 * 6360.0), M_PI_2);
-            const double chord = 2.0 * std::sin(half);
-            sa.far2 = (std::isfinite(dmax) && dmax >= 0.0) ? chord * chord : __builtin_inf();
-        }
-        hipLaunchKernelGGL(seed_search_kernel, dim3(nblocks(nP, kBlock / 64)), dim3(kBlock), 0, h->stream, sa);
+        uint32_t *kb = nullptr;
+        double *db = nullptr;
+        rc = nearest_search(h, nP, d_ll, d_lat, d_lon, resolkm, 2.5, 10, &w, &kb, &db);
+        if (rc) return rc;
         hipLaunchKernelGGL(seed_finish_kernel, dim3(nblocks(nP)), dim3(kBlock), 0, h->stream, nP, h->Nj, h->Ni, kb, db, d_yx,
                            resolkm ? d_res : nullptr, d_sic, h->tmask, h->geo, h->rmin_conc, 2.5, 10, d_ji, d_keep, d_why);
         hipError_t le = hipGetLastError();
@@ -818,6 +835,72 @@ SITRK_API int sitrk_seed_init(sitrk_t *h, int64_t nP, const double *latlon, cons
     HIPCHK(hipMemcpyAsync(jiT_out, d_ji, (size_t)nP * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(keep, d_keep, (size_t)nP, hipMemcpyDeviceToHost, h->stream));
     if (why) HIPCHK(hipMemcpyAsync(why, d_why, (size_t)nP, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SITRK_OK;
+}
+
+SITRK_API int sitrk_nearest_point(sitrk_t *h, int64_t nP, const double *latlon, const double *latT, const double *lonT,
+                                  const double *resolkm, double rd_found_km, int max_itr, int32_t *ji_out, double *dmin_out)
+{
+    NEED(h, "null handle");
+    NEED(h->geo, "sitrk_nearest_point: call sitrk_set_grid first");
+    NEED(nP >= 0, "sitrk_nearest_point: nP < 0");
+    NEED(max_itr >= 1, "sitrk_nearest_point: max_itr must be >= 1");
+    if (nP == 0) return SITRK_OK;
+    NEED(latlon && latT && lonT && ji_out, "sitrk_nearest_point: null array");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t n = (size_t)h->Nj * h->Ni;
+    const size_t b_pt = align256((size_t)nP * sizeof(ll)), b_g = align256(n * 8), b_ji = align256((size_t)nP * 8),
+                 b_d = align256((size_t)nP * 8);
+    int rc = ensure_scratch(h, b_pt + 3 * b_g + b_ji + b_d);
+    if (rc) return rc;
+    char *s = (char *)h->scratch;
+    ll *d_ll = (ll *)s;                 s += b_pt;
+    double *d_lat = (double *)s;        s += b_g;
+    double *d_lon = (double *)s;        s += b_g;
+    double *d_res = (double *)s;        s += b_g;
+    int32_t *d_ji = (int32_t *)s;       s += b_ji;
+    double *d_dm = (double *)s;
+    HIPCHK(hipMemcpyAsync(d_ll, latlon, (size_t)nP * sizeof(ll), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_lat, latT, n * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_lon, lonT, n * 8, hipMemcpyHostToDevice, h->stream));
+    if (resolkm) HIPCHK(hipMemcpyAsync(d_res, resolkm, n * 8, hipMemcpyHostToDevice, h->stream));
+    char *w = nullptr;
+    uint32_t *kb = nullptr;
+    double *db = nullptr;
+    rc = nearest_search(h, nP, d_ll, d_lat, d_lon, resolkm, rd_found_km, max_itr, &w, &kb, &db);
+    if (rc) return rc;
+    hipLaunchKernelGGL(nearest_finish_kernel, dim3(nblocks(nP)), dim3(kBlock), 0, h->stream, nP, h->Ni, kb, db,
+                       resolkm ? d_res : nullptr, rd_found_km, max_itr, d_ji, d_dm);
+    hipError_t le = hipGetLastError();
+    hipError_t se = hipStreamSynchronize(h->stream);
+    (void)hipFree(w);
+    if (le != hipSuccess) return fail(h, SITRK_EHIP, "nearest-point launch -> %s", hipGetErrorString(le));
+    if (se != hipSuccess) return fail(h, SITRK_EHIP, "nearest-point search -> %s", hipGetErrorString(se));
+    HIPCHK(hipMemcpyAsync(ji_out, d_ji, (size_t)nP * 8, hipMemcpyDeviceToHost, h->stream));
+    if (dmin_out) HIPCHK(hipMemcpyAsync(dmin_out, d_dm, (size_t)nP * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SITRK_OK;
+}
+
+SITRK_API int sitrk_eval_haversine(sitrk_t *h, int64_t n, const double *plat, const double *plon, const double *xlat,
+                                   const double *xlon, double *dist)
+{
+    NEED(h, "null handle");
+    NEED(n >= 0, "sitrk_eval_haversine: n < 0");
+    if (n == 0) return SITRK_OK;
+    NEED(plat && plon && xlat && xlon && dist, "sitrk_eval_haversine: null array");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t b = align256((size_t)n * 8);
+    int rc = ensure_scratch(h, 5 * b);
+    if (rc) return rc;
+    char *s = (char *)h->scratch;
+    const double *src[4] = {plat, plon, xlat, xlon};
+    for (int a = 0; a < 4; a++) HIPCHK(hipMemcpyAsync(s + a * b, src[a], (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(eval_haversine_kernel, dim3(nblocks(n)), dim3(kBlock), 0, h->stream, n, (const double *)s, (const double *)(s + b),
+                       (const double *)(s + 2 * b), (const double *)(s + 3 * b), (double *)(s + 4 * b));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(dist, s + 4 * b, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return SITRK_OK;
 }

@@ -315,4 +315,43 @@ __global__ void seed_finish_kernel(int64_t nP, int Nj, int Ni, const uint32_t *_
     if (why) why[p] = wy;
 }
 
+// NearestPoint alone (locate.py:222-276, whole-domain form): nearest T-point of every seed, or (-1,-1) when the
+// acceptance loop gives up; same loop as in seed_finish_kernel
+__global__ void nearest_finish_kernel(int64_t nP, int Ni, const uint32_t *__restrict__ kbest, const double *__restrict__ dbest,
+                                      const double *__restrict__ resol, double rd_found_km, int max_itr,
+                                      int32_t *__restrict__ ji, double *__restrict__ dmin)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nP) return;
+    const uint32_t k = kbest[p];
+    int jy = -1, jx = -1;
+    double best = __builtin_inf();
+    if (k != 0xffffffffu) {
+        best = dbest[p];
+        double rfnd = rd_found_km;
+        bool lfound = false;
+        int igo = 0;
+        while (!lfound && igo < max_itr) {
+            igo = igo + 1;
+            if (igo == 1 && resol) rfnd = 0.5 * resol[k];
+            if (igo == 1) igo = 2;
+            lfound = (best < rfnd);
+            if (igo > 1 && !lfound) rfnd = 1.2 * rfnd;
+        }
+        if (igo != max_itr) { jy = (int)(k / (uint32_t)Ni); jx = (int)(k % (uint32_t)Ni); }
+    }
+    ji[2 * p] = jy; ji[2 * p + 1] = jx;
+    if (dmin) dmin[p] = best;
+}
+
+// Haversine (util.py:85-103) element by element
+__global__ void eval_haversine_kernel(int64_t n, const double *__restrict__ plat, const double *__restrict__ plon,
+                                      const double *__restrict__ xlat, const double *__restrict__ xlon, double *__restrict__ out)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const double to_rad = 3.141592653589793 / 180.;
+    out[k] = haversine(plat[k], plon[k], cos(plat[k] * to_rad), xlat[k], xlon[k]);
+}
+
 }  // namespace sitrk

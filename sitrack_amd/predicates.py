@@ -124,6 +124,32 @@ def UpdtInd4NewCell(knhc, ji4vert, kjiT, iverbose=0):
     return ji4vert, kjiT
 
 
+def Haversine(plat, plon, xlat, xlon, ctx=None):
+    """reference util.py:85-103: distance [km] between the point (plat,plon) and every point of (xlat,xlon), R = 6360 km."""
+    xlat = np.asarray(xlat, dtype=np.float64)
+    return _default(ctx).eval_haversine(float(plat), float(plon), xlat, np.asarray(xlon, dtype=np.float64)).reshape(xlat.shape)
+
+
+def NearestPoint(pntGcoor, pLat, pLon, rd_found_km=10., resolkm=[], ji_prv=(), np_box_r=10, max_itr=5, ctx=None):
+    """reference locate.py:222-276: (j,i) of the grid point nearest to `pntGcoor` = (lat,lon), (-1,-1) if the acceptance
+    loop gives up.  Whole-domain search only, as SeedInit uses it: the `ji_prv` / `np_box_r` local-box variant is not
+    offered (ValueError)."""
+    if len(ji_prv) != 0:
+        raise ValueError("NearestPoint: the local search around ji_prv is not part of this build (SeedInit does not use it)")
+    lat = np.ascontiguousarray(pLat, dtype=np.float64)
+    lon = np.ascontiguousarray(pLon, dtype=np.float64)
+    if lon.shape != lat.shape:
+        print('ERROR [NearestPoint]: `pLat` & `pLon` do not have the same shape!')
+        raise SystemExit(0)
+    c = ctx if ctx is not None else _scratch()
+    if ctx is None:
+        z = np.zeros(lat.shape)
+        c.set_grid(z, z, z, z, z, z, np.ones(lat.shape, dtype=np.int8))
+    res = np.asarray(resolkm, dtype=np.float64) if np.shape(resolkm) == lat.shape else None       # `l2Dresol` of the reference
+    ji, _ = c.nearest_point(np.array([[float(pntGcoor[0]), float(pntGcoor[1])]]), lat, lon, res, rd_found_km, max_itr)
+    return (int(ji[0, 0]), int(ji[0, 1]))
+
+
 def Survive(kID, kjiT, pmskT, pIceC=[], iverbose=0, ctx=None):
     """reference tracking.py:62-93: 1 = kill (domain rim, land-sea mask stencil, 5-point mean ice concentration
     < rmin_conc), 0 = survive.  Like the reference, fails with UnboundLocalError when a buoy passes the first two

@@ -65,3 +65,33 @@ def test_survive_scalar(sit, golden, capsys):
     assert sit.Survive(7, [0, 5], g["tmask"], iverbose=1) == 1 and "CANCEL buoy 7" in capsys.readouterr().out
     with pytest.raises(IndexError):
         sit.Survive(7, [g["tmask"].shape[0], 5], g["tmask"], g["sic"])
+
+
+def test_nearest_point_and_haversine_scalars(sit, golden):
+    """locate.NearestPoint as SeedInit calls it (tracking.py:134) and with a plain radius; util.Haversine."""
+    g = golden("g5_seedinit.npz")
+    for k in range(0, len(g["ids"]), 5):
+        jy, jx = sit.NearestPoint((g["pSG"][k, 0], g["pSG"][k, 1]), g["latT"], g["lonT"], rd_found_km=sit.rFoundKM,
+                                  resolkm=g["resol"], max_itr=10)
+        assert (jy, jx) == tuple(g["nearest"][k]), k
+    plain = np.array([sit.NearestPoint((g["pSG"][k, 0], g["pSG"][k, 1]), g["latT"], g["lonT"], rd_found_km=8., max_itr=5)
+                      for k in range(0, len(g["ids"]), 7)])
+    assert np.array_equal(plain, g["nearest_plain"])
+    assert (g["nearest"] < 0).any() and (g["nearest_plain"] < 0).any()            # both outcomes are in the vectors
+    with pytest.raises(ValueError):
+        sit.NearestPoint((80., 10.), g["latT"], g["lonT"], ji_prv=(3, 4))
+    # the whole batch through the context method: indices and distances
+    ctx = sit.Context(0)
+    z = np.zeros_like(g["latT"])
+    ctx.set_grid(z, z, z, z, z, z, np.ones(z.shape, dtype=np.int8))
+    ji, dmin = ctx.nearest_point(g["pSG"], g["latT"], g["lonT"], g["resol"], sit.rFoundKM, 10)
+    assert np.array_equal(ji, g["nearest"])
+    near = np.isfinite(dmin)                                                     # far seeds are rejected without a search
+    assert np.all(ji[~near] == -1) and np.allclose(dmin[near], g["dmin"][near], rtol=1e-12, atol=1e-9)
+    ctx.close()
+    h = golden("g9_haversine.npz")
+    for k in range(0, 4000, 400):
+        d = sit.Haversine(h["plat"][k], h["plon"][k], h["xlat"][k:k + 50], h["xlon"][k:k + 50])
+        assert d.shape == (50,) and abs(d[0] - h["dist"][k]) <= 1e-9 + 1e-12 * h["dist"][k]
+    d2 = sit.Haversine(75., 20., g["latT"], g["lonT"])
+    assert d2.shape == g["latT"].shape and d2.min() >= 0
