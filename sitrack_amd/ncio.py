@@ -86,11 +86,8 @@ class _Reader:
 
 
 def _project(ctx, lat, lon):
-    """ConvertGeo2CartesianNPSkm (reference util.py:434-451): lat/lon (deg, 2-D) -> (Y, X) km, lat_ts 70, lon_0 -45."""
-    shp = np.shape(lat)
-    ll = np.stack([np.asarray(lat, dtype=np.float64).ravel(), np.asarray(lon, dtype=np.float64).ravel()], axis=1)
-    yx = ctx.geo2cart(ll, 70., -45.)
-    return np.ascontiguousarray(yx[:, 0].reshape(shp)), np.ascontiguousarray(yx[:, 1].reshape(shp))
+    from .tracking import ConvertGeo2CartesianNPSkm
+    return ConvertGeo2CartesianNPSkm(lat, lon, 70., -45., ctx=ctx)
 
 
 def GetModelGrid(fNCmeshmask, ctx):

@@ -117,6 +117,25 @@ def Geo2CartNPSkm1D(pcoorG, lat0=70., lon0=-45., ctx=None):
     return (ctx or default_context()).geo2cart(pcoorG, lat0, lon0)
 
 
+def ConvertGeo2CartesianNPSkm(plat, plon, lat0=70., lon0=-45., ctx=None):
+    """reference util.py:434-451: geographic (lat, lon) [deg], any shape -> (Y, X) [km] of the WGS84 north polar
+    stereographic plane (true-scale latitude lat0, central longitude lon0), same shape.  Projection on the device."""
+    ctx = ctx or default_context()
+    shp = np.shape(plat)
+    ll = np.stack([np.asarray(plat, dtype=np.float64).ravel(), np.asarray(plon, dtype=np.float64).ravel()], axis=1)
+    yx = ctx.geo2cart(ll, lat0, lon0)
+    return np.ascontiguousarray(yx[:, 0].reshape(shp)), np.ascontiguousarray(yx[:, 1].reshape(shp))
+
+
+def ConvertCartesianNPSkm2Geo(pY, pX, lat0=70., lon0=-45., ctx=None):
+    """reference util.py:455-472: the inverse, (Y, X) [km] -> (lat, lon) [deg], same shape."""
+    ctx = ctx or default_context()
+    shp = np.shape(pX)
+    yx = np.stack([np.asarray(pY, dtype=np.float64).ravel(), np.asarray(pX, dtype=np.float64).ravel()], axis=1)
+    ll = ctx.cart2geo(yx, lat0, lon0)
+    return np.ascontiguousarray(ll[:, 0].reshape(shp)), np.ascontiguousarray(ll[:, 1].reshape(shp))
+
+
 class IceTracker:
     """The record loop body of the reference driver (si3_part_tracker.py:361-496) as an object.
 

@@ -95,3 +95,16 @@ def test_nearest_point_and_haversine_scalars(sit, golden):
         assert d.shape == (50,) and abs(d[0] - h["dist"][k]) <= 1e-9 + 1e-12 * h["dist"][k]
     d2 = sit.Haversine(75., 20., g["latT"], g["lonT"])
     assert d2.shape == g["latT"].shape and d2.min() >= 0
+
+
+def test_projection_2d_helpers(sit, golden):
+    """util.ConvertGeo2CartesianNPSkm / ConvertCartesianNPSkm2Geo: the reference's committed seeding file pins the
+    forward map at float32 (G7); the inverse is held to the forward by round trip."""
+    g = golden("g7_projection.npz")
+    lon = g["dat_lonlat"][:, 0].reshape(2, 5); lat = g["dat_lonlat"][:, 1].reshape(2, 5)      # tools/sidfexloc.dat values
+    Y, X = sit.ConvertGeo2CartesianNPSkm(lat, lon)
+    assert Y.shape == (2, 5) and X.shape == (2, 5)
+    assert np.array_equal(Y.astype(np.float32).ravel(), g["y_pos"]) and np.array_equal(X.astype(np.float32).ravel(), g["x_pos"])
+    la2, lo2 = sit.ConvertCartesianNPSkm2Geo(Y, X)
+    dlon = (lo2 - lon + 180.) % 360. - 180.
+    assert np.allclose(la2, lat, rtol=0, atol=1e-9) and np.allclose(dlon, 0., rtol=0, atol=1e-9)
