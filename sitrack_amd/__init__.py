@@ -9,4 +9,6 @@ from .tracking import (SeedInit, FindContainingCell, CartNPSkm2Geo1D, Geo2CartNP
                        IceTracker, vertices_of, default_context, rmin_conc, rFoundKM)
 from .predicates import (_ccw_, intersect2Seg, IsInsideQuadrangle, CrossedEdge, NewHostCell, UpdtInd4NewCell,  # noqa: F401
                          Survive, Haversine, NearestPoint)
+from .ncio import (GetModelGrid, GetModelUVGrid, LoadNCtime, LoadNCdata, SeedFileTimeInfo, ModelFileTimeInfo,  # noqa: F401
+                   ncSaveCloudBuoys, chck4f)
 from . import synthetic                                                      # noqa: F401

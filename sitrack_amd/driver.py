@@ -139,9 +139,9 @@ def main(argv=None):
             os.makedirs(cd, exist_ok=True)
 
     ctx = _lib.Context(a.device if comm.world == 1 else comm.device)
-    imaskt, xlatT, xlonT, xYt, xXt, xYf, xXf, xResKM = ncio.GetModelGrid(cf_mm, ctx)
+    imaskt, xlatT, xlonT, xYt, xXt, xYf, xXf, xResKM = ncio.GetModelGrid(cf_mm, ctx=ctx)
     if iUVstrategy >= 1:
-        xYv, xXv, xYu, xXu = ncio.GetModelUVGrid(cf_mm, ctx)
+        xYv, xXv, xYu, xXu = ncio.GetModelUVGrid(cf_mm, ctx=ctx)
     else:
         xYv, xXv, xYu, xXu = xYf, xXf, xYf, xXf     # never read by the cell-mean rule
     (Nj, Ni) = np.shape(imaskt)

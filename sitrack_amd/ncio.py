@@ -90,9 +90,19 @@ def _project(ctx, lat, lon):
     return ConvertGeo2CartesianNPSkm(lat, lon, 70., -45., ctx=ctx)
 
 
-def GetModelGrid(fNCmeshmask, ctx):
-    """Reference ncio.py:22-63 -> kmaskt, zlatT, zlonT, zYt, zXt, zYf, zXf, zResKM."""
+def _ctx_or_default(ctx):
+    if ctx is not None:
+        return ctx
+    from .tracking import default_context
+    return default_context()
+
+
+def GetModelGrid(fNCmeshmask, alsoF=False, ctx=None):
+    """Reference ncio.py:22-63 -> kmaskt, zlatT, zlonT, zYt, zXt, zYf, zXf, zResKM (+ kmaskf, zlatF, zlonF with alsoF).
+    `ctx` (extra, optional): the context whose GPU projects the coordinates; default = the process-wide one."""
+    ctx = _ctx_or_default(ctx)
     with _Reader(fNCmeshmask) as f:
+        kmaskf = f.var('fmask', (0, 0)) if alsoF else None
         kmaskt = f.var('tmask', (0, 0))
         zlonF = f.var('glamf', 0); zlatF = f.var('gphif', 0)
         zlonT = f.var('glamt', 0); zlatT = f.var('gphit', 0)
@@ -105,11 +115,14 @@ def GetModelGrid(fNCmeshmask, ctx):
     zYt, zXt = _project(ctx, zlatT, zlonT)
     zYf, zXf = _project(ctx, zlatF, zlonF)
     zResKM = np.sqrt(ze1T * ze1T + ze2T * ze2T).astype(np.float64)
+    if alsoF:
+        return kmaskt, zlatT, zlonT, zYt, zXt, zYf, zXf, zResKM, kmaskf, zlatF, zlonF
     return kmaskt, zlatT, zlonT, zYt, zXt, zYf, zXf, zResKM
 
 
-def GetModelUVGrid(fNCmeshmask, ctx):
+def GetModelUVGrid(fNCmeshmask, ctx=None):
     """Reference ncio.py:66-92 -> zYv, zXv, zYu, zXu."""
+    ctx = _ctx_or_default(ctx)
     with _Reader(fNCmeshmask) as f:
         zlonV = f.var('glamv', 0); zlatV = f.var('gphiv', 0)
         zlonU = f.var('glamu', 0); zlatU = f.var('gphiu', 0)

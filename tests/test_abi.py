@@ -56,6 +56,33 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
         assert r.returncode == 3 and "no HIP device" in r.stdout, r.stdout + r.stderr
 
 
+def test_host_mirror_carries_the_names_the_reference_driver_uses():
+    """`import sitrack_amd as sit`: every `sit.<name>` si3_part_tracker.py of the reference refers to exists here
+    (all but `PlotMesh`: plotting is out of scope), plus the functions its SeedInit is built from."""
+    import inspect
+    import sitrack_amd as sit
+    for name in ("CartNPSkm2Geo1D", "CrossedEdge", "FillValue", "GetModelGrid", "GetModelUVGrid", "GetTimeSpan",
+                 "IsInsideQuadrangle", "LoadNCdata", "ModelFileTimeInfo", "NewHostCell", "SeedFileTimeInfo", "SeedInit",
+                 "Survive", "UpdtInd4NewCell", "intersect2Seg", "ncSaveCloudBuoys",
+                 "NearestPoint", "Haversine", "FindContainingCell", "Geo2CartNPSkm1D", "ConvertGeo2CartesianNPSkm",
+                 "ConvertCartesianNPSkm2Geo", "_ccw_"):
+        assert hasattr(sit, name), name
+    # positional parameters in the reference's order (extras only after them, keyword `ctx`)
+    want = {"SeedInit": ["pIDs", "pSG", "pSC", "platT", "plonT", "pYf", "pXf", "pResolKM", "maskT", "xIceConc", "iverbose"],
+            "Survive": ["kID", "kjiT", "pmskT", "pIceC", "iverbose"],
+            "CrossedEdge": ["pP1", "pP2", "ji4vert", "pY", "pX", "iverbose"],
+            "NewHostCell": ["kcross", "pP1", "pP2", "ji4vert", "pY", "pX", "iverbose"],
+            "UpdtInd4NewCell": ["knhc", "ji4vert", "kjiT", "iverbose"],
+            "IsInsideQuadrangle": ["y", "x", "quad"],
+            "intersect2Seg": ["pcA", "pcB", "pcC", "pcD"],
+            "NearestPoint": ["pntGcoor", "pLat", "pLon", "rd_found_km", "resolkm", "ji_prv", "np_box_r", "max_itr"],
+            "GetTimeSpan": ["dt", "vtime_mod", "iSdA", "iMdA", "iMdB", "iStop", "iverbose"],
+            "CartNPSkm2Geo1D": ["pcoorC", "lat0", "lon0"], "GetModelGrid": ["fNCmeshmask", "alsoF"], "GetModelUVGrid": ["fNCmeshmask"]}
+    for name, params in want.items():
+        got = list(inspect.signature(getattr(sit, name)).parameters)
+        assert got[:len(params)] == params, (name, got)
+
+
 def test_constant_division_identity_on_cpu(tmp_path):
     """The hot loop evaluates `/1000.` as mul + 2 fma (sitrk_geom.h::div1000).  Same IEEE operations on the host:
     random values, the values closest to rounding midpoints, binade edges - all equal to the true quotient."""

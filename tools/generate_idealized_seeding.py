@@ -43,7 +43,7 @@ def main(argv=None):
         return write_seeding(ctx, a, seeding_type, XseedGC, zIDs)
     if not a.fmmm:
         raise SystemExit('ERROR: you have to specify a MeshMask file with `-m`')
-    imaskt, xlatT, xlonT, xYt, xXt, xYf, xXf, xResKM = ncio.GetModelGrid(a.fmmm, ctx)
+    imaskt, xlatT, xlonT, xYt, xXt, xYf, xXf, xResKM = ncio.GetModelGrid(a.fmmm, ctx=ctx)
     if a.fsi3:
         rec = ncio.ModelRecords(a.fsi3)
         (xIC,) = rec.fields(a.krec, (a.nsic,))
