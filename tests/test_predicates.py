@@ -108,3 +108,54 @@ def test_projection_2d_helpers(sit, golden):
     la2, lo2 = sit.ConvertCartesianNPSkm2Geo(Y, X)
     dlon = (lo2 - lon + 180.) % 360. - 180.
     assert np.allclose(la2, lat, rtol=0, atol=1e-9) and np.allclose(dlon, 0., rtol=0, atol=1e-9)
+
+
+def test_the_loop_body_written_against_sit_reproduces_the_reference_trajectories(sit, golden):
+    """A per-buoy loop in the order of si3_part_tracker.py:378-490 whose `sit.*` calls land in THIS package, on the
+    inputs of golden set G6 (trajectories the reference's own functions produced in that loop): same positions, masks,
+    cells and deaths, bit for bit.  32 buoys x 24 records; every predicate call is one round trip to the GPU."""
+    from sitrack_amd import synthetic as syn
+    g = golden("g6_traj_curvi.npz")
+    grid = syn.make_grid(int(g["Nj"]), int(g["Ni"]), dkm=float(g["dkm"]), warp=float(g["warp"]))
+    xYf, xXf, xYu, xXu, xYv, xXv = (grid[k] for k in ("Yf", "Xf", "Yu", "Xu", "Yv", "Xv"))
+    K, kstrt, rdt, Nt = g["u"].shape[0], int(g["kstrt"]), float(g["rdt"]), 24
+    sel = np.arange(0, 128, 4)
+    nP = len(sel)
+    z1st, zLst = g["rec_first"][sel], g["rec_last"][sel]
+    vJIt = g["jiT0"][sel].copy(); VRTCS = g["vert0"][sel].copy()
+    iAlive = np.ones(nP, dtype='i1')
+    xPosC = np.zeros((Nt + 1, nP, 2)) + sit.FillValue
+    xmask = np.zeros((Nt + 1, nP), dtype='i1')
+    for jP in range(nP):
+        xPosC[z1st[jP] - kstrt, jP] = g["yx0"][sel[jP]]; xmask[z1st[jP] - kstrt, jP] = 1
+    vMesh = np.zeros((nP, 4, 2)); lStillIn = np.zeros(nP, dtype=bool)
+    ncross = 0
+    for jt in range(Nt):
+        jrec = jt + kstrt
+        xUu = g["u"][jrec % K].astype(np.float64); xVv = g["v"][jrec % K].astype(np.float64); xIC = g["sic"][jrec % K].astype(np.float64)
+        for jP in range(nP):
+            if iAlive[jP] == 1 and z1st[jP] <= jrec <= zLst[jP]:
+                ry, rx = xPosC[jt, jP]
+                if not lStillIn[jP]:
+                    vj, vi = VRTCS[jP]
+                    vMesh[jP] = np.stack([xYf[vj, vi], xXf[vj, vi]], axis=1)
+                jT, iT = vJIt[jP]
+                zF = [xYf[jT, iT], xXf[jT, iT]]
+                llum1 = sit.intersect2Seg([ry, rx], zF, [xYv[jT - 1, iT], xXv[jT - 1, iT]], [xYv[jT, iT], xXv[jT, iT]])
+                llvm1 = sit.intersect2Seg([ry, rx], zF, [xYu[jT, iT - 1], xXu[jT, iT - 1]], [xYu[jT, iT], xXu[jT, iT]])
+                zU = xUu[jT, iT - 1] if llum1 else xUu[jT, iT]
+                zV = xVv[jT - 1, iT] if llvm1 else xVv[jT, iT]
+                dx = zU * rdt; dy = zV * rdt
+                rx_nxt = rx + dx / 1000.; ry_nxt = ry + dy / 1000.
+                xPosC[jt + 1, jP] = [ry_nxt, rx_nxt]; xmask[jt + 1, jP] = 1
+                lStillIn[jP] = sit.IsInsideQuadrangle(ry_nxt, rx_nxt, vMesh[jP])
+                if not lStillIn[jP]:
+                    icross = sit.CrossedEdge([ry, rx], [ry_nxt, rx_nxt], VRTCS[jP], xYf, xXf)
+                    inhc = sit.NewHostCell(icross, [ry, rx], [ry_nxt, rx_nxt], VRTCS[jP], xYf, xXf)
+                    VRTCS[jP], vJIt[jP] = sit.UpdtInd4NewCell(inhc, VRTCS[jP], vJIt[jP])
+                    ncross += 1
+                    if sit.Survive(jP, vJIt[jP], g["tmask"], pIceC=xIC) > 0:
+                        iAlive[jP] = 0
+        assert np.array_equal(vJIt, g["jiT_s1"][jt + 1][sel]) and np.array_equal(iAlive, g["alive_s1"][jt + 1][sel]), jt
+    assert np.array_equal(xPosC, g["pos_s1"][:Nt + 1, sel]) and np.array_equal(xmask, g["msk_s1"][:Nt + 1, sel])
+    assert ncross > 40 and (iAlive == 0).any()
