@@ -301,16 +301,16 @@ def ncSaveCloudBuoys(cf_out, ptime, pIDs, pY, pX, pLat, pLon, mask=[], xtime=[],
         x_tim.units = tunits
     v_buoy[:] = np.arange(Nb, dtype='i4')
     v_bid[:] = np.asarray(pIDs)[:]
-    for jt in range(Nt):
-        v_time[jt] = int(ptime[jt])
-        x_lat[jt, :] = np.asarray(pLat[jt, :], dtype=np.float32)
-        x_lon[jt, :] = np.asarray(pLon[jt, :], dtype=np.float32)
-        x_ykm[jt, :] = np.asarray(pY[jt, :], dtype=np.float32)
-        x_xkm[jt, :] = np.asarray(pX[jt, :], dtype=np.float32)
-        if lSaveMask:
-            v_mask[jt, :] = np.asarray(mask[jt, :], dtype='i1')
-        if lSaveTime:
-            x_tim[jt, :] = np.asarray(xtime[jt, :]).astype('i4')
+    # whole arrays at once (the reference writes record by record; the NetCDF-3 writer would re-allocate per record)
+    v_time[:] = np.asarray(ptime).astype('i4')
+    x_lat[:, :] = np.asarray(pLat, dtype=np.float32)
+    x_lon[:, :] = np.asarray(pLon, dtype=np.float32)
+    x_ykm[:, :] = np.asarray(pY, dtype=np.float32)
+    x_xkm[:, :] = np.asarray(pX, dtype=np.float32)
+    if lSaveMask:
+        v_mask[:, :] = np.asarray(mask, dtype='i1')
+    if lSaveTime:
+        x_tim[:, :] = np.asarray(xtime).astype('i4')
     if corigin:
         f.Origin = corigin
     f.About = about

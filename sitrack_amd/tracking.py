@@ -164,7 +164,9 @@ class IceTracker:
         dt = self.ctx.field_dtype
         for nm, a in (("u_ice", xUu), ("v_ice", xVv), ("siconc", xIC)):
             a = np.asarray(a)
-            if a.dtype != dt and not np.array_equal(a.astype(dt).astype(a.dtype), a, equal_nan=True):
+            if a.dtype.newbyteorder('=') == dt:              # same type up to byte order (NetCDF-3 data are big-endian)
+                continue
+            if not np.array_equal(a.astype(dt).astype(a.dtype), a, equal_nan=True):
                 raise ValueError("%s is not exactly representable as %s; allocate float64 records" % (nm, dt))
 
     def load_record(self, slot, xUu, xVv, xIC):
