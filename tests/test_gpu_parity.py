@@ -603,3 +603,36 @@ def test_errors(ctx):
         ctx.set_params(3600., 3, 0.1)           # 0, 1 = the reference's rules, 2 = the extra
     with pytest.raises(ValueError):
         ctx.push_record(0, np.zeros((3, 3)), np.zeros((3, 3)), np.zeros((3, 3)))
+
+
+def test_contexts_release_their_device_memory():
+    """40 full life cycles (grid, records, buoys, sort, fused run, SeedInit-style search, fetch, destroy): the free
+    device memory at the end is where it was (torch only reads the counter)."""
+    import torch
+    grid = syn.make_grid(384, 400, dkm=4.0, warp=1.0)
+    u, v, sic = syn.make_fields(grid, K=4, seed=3, umax=0.5, drift=0.1)
+    _, yx = syn.make_buoys(grid, 150000, seed=4, frac=0.7)
+    guess = syn.nearest_t_plane(grid, yx).astype(np.int32)
+
+    def cycle():
+        c = sit.Context(0)
+        c.set_grid(grid["Yf"], grid["Xf"], grid["Yu"], grid["Xu"], grid["Yv"], grid["Xv"], grid["tmask"])
+        c.alloc_records(4, np.float32)
+        for k in range(4):
+            c.push_record(k, u[k], v[k], sic[k])
+        found, ji = c.find_cells(yx, guess)
+        c.set_buoys(yx[found], ji[found])
+        c.run(0, 0, 20)
+        c.nearest_point(np.array([[80., 10.], [75., -30.]]), np.full(grid["Yf"].shape, 80.), np.full(grid["Yf"].shape, 10.), None, 2.5, 10)
+        st = c.fetch()
+        c.close()
+        return st["yx"]
+
+    first = cycle()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(0)
+    for _ in range(40):
+        assert np.array_equal(cycle(), first)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(0)
+    assert free0 - free1 < 64 << 20, (free0, free1)
