@@ -636,3 +636,43 @@ def test_contexts_release_their_device_memory():
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info(0)
     assert free0 - free1 < 64 << 20, (free0, free1)
+
+
+def test_two_contexts_in_two_threads():
+    """One host thread per context, no global state: two trackers stepped concurrently from two
+    threads (ctypes releases the GIL during the calls) give what each gives alone."""
+    import threading
+    grid = syn.make_grid(160, 176, dkm=4.0, warp=1.0)
+    cases = []
+    for seed in (1, 2):
+        u, v, sic = syn.make_fields(grid, K=4, seed=seed, umax=0.8, drift=0.2, ripple=0.1)
+        _, yx = syn.make_buoys(grid, 80000, seed=10 + seed, frac=0.75)
+        cases.append((u, v, sic, yx))
+
+    def run(case, out, idx, nrep):
+        u, v, sic, yx = case
+        for _ in range(nrep):
+            trk = make_tracker(grid, grid["tmask"], 4, iUVstrategy=idx % 2)
+            found, ji, _ = sit.FindContainingCell(yx, syn.nearest_t_plane(grid, yx), ctx=trk.ctx)
+            trk.set_buoys(yx[found], ji[found])
+            for k in range(4):
+                trk.load_record(k, u[k], v[k], sic[k])
+            for s in range(0, 48, 6):
+                trk.ctx.run(s % 4, s, 5)
+                trk.step(s + 5, (s + 5) % 4)
+                trk.record(s + 5, latlon=True)
+            out[idx] = trk.state()
+            trk.close()
+
+    alone = [None, None]
+    for i in (0, 1):
+        run(cases[i], alone, i, 1)
+    both = [None, None]
+    th = [threading.Thread(target=run, args=(cases[i], both, i, 3)) for i in (0, 1)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in (0, 1):
+        for key in ("yx", "vJIt", "iAlive", "kill_rec"):
+            assert np.array_equal(both[i][key], alone[i][key]), (i, key)
