@@ -180,3 +180,23 @@ def test_bench_two_ranks_as_the_driver_launches_it():
     assert d["n_gpus"] == 2 and d["steps"] == 40 and d["warmup"] == 8 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["buoys_per_gpu"] == 100000 and "broadcast from rank 0" in d["config"]["records_via"]
     assert abs(d["value"] - 2 * 100000 * 40 / (d["ms_per_step"] * 40e-3)) < 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--e2e-full"]])
+def test_bench_end_to_end_regime_checks_against_the_oracle(extra):
+    """bench.py --regime e2e (every record uploaded from pinned host memory on a copy stream, double-buffered against the
+    stepping on a second stream, row bands or whole records): the run's own --check replays it on the oracle."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "bench.py", "--config", "c2", "--regime", "e2e", "--steps", "60", "--warmup", "5", "--check",
+           "--no-cpu-baseline"] + extra
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "check OK" in r.stderr, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["regime"] == "e2e" and d["value"] > 0 and d["config"]["e2e_upload_bytes_per_step"] > 0
+    full = 3 * 512 * 512 * 4
+    assert (d["config"]["e2e_upload_bytes_per_step"] == full) == bool(extra)
