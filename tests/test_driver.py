@@ -48,6 +48,21 @@ def test_record_windows():
     # hand-evaluated from reference si3_part_tracker.py:289-312 (strict comparisons against record centres +- rdt/2)
     assert list(z1) == [0, 4, 2]
     assert list(zL) == [23, 12, 23]
+    # the all-buoys-at-once form on an increasing time axis == the reference's per-buoy np.where loop, incl. times
+    # exactly on the +-rdt/2 boundaries
+    rng = np.random.default_rng(3)
+    n = 4000
+    zT = np.stack([rng.integers(vt[0] - 7200, vt[-1] + 1800, n), rng.integers(vt[0] + 1800, vt[-1] + 7200, n)])
+    zT[0, ::9] = vt[rng.integers(0, 24, len(zT[0, ::9]))] + rng.choice([-1800, 1800, 0, 1799, 1801], len(zT[0, ::9]))
+    zT[1, ::7] = vt[rng.integers(0, 24, len(zT[1, ::7]))] + rng.choice([-1800, 1800, 0, -1799, -1801], len(zT[1, ::7]))
+    zT[0][zT[0] == iTmA + 1800] += 1                       # (exactly there the reference's own search comes back empty)
+    fast = drv.record_windows(zT, vt, kstrt, kstop, iTmA, iTmB, n)
+    late = np.where(zT[0] >= iTmA + 1800)[0]; early = np.where(zT[1] < iTmB - 1800)[0]
+    slow = drv._record_windows_loop(zT, vt, np.zeros(n, dtype=int) + kstrt, np.zeros(n, dtype=int) + kstop, late, early, 1800)
+    assert np.array_equal(fast[0], slow[0]) and np.array_equal(fast[1], slow[1])
+    with pytest.raises(IndexError):
+        drv.record_windows(np.array([[iTmA + 1800], [iTmB]]), vt, kstrt, kstop, iTmA, iTmB, 1)
+    assert len(np.unique(fast[0])) > 10 and len(np.unique(fast[1])) > 10
 
 
 def test_ncio_schema_and_roundtrip_both_backends(tmp_path, monkeypatch):
