@@ -25,7 +25,12 @@ except Exception:                                          # noqa: BLE001
 
 
 def backend():
-    return "netCDF4" if _nc4 is not None else "scipy-netcdf3"
+    """What reads and writes: netCDF4 when importable; otherwise NetCDF-4/HDF5 inputs are read through the system's
+    libhdf5 (h5lite.py), classic inputs through scipy, and outputs are written as NetCDF-3."""
+    if _nc4 is not None:
+        return "netCDF4"
+    from . import h5lite
+    return "scipy-netcdf3" + (" + libhdf5 reader" if h5lite.available() else "")
 
 
 def chck4f(cf):
@@ -40,22 +45,34 @@ class _Reader:
         chck4f(cfile)
         self.nc4 = None
         self.sp = None
+        self.h5 = None
         if _nc4 is not None:
             try:
                 self.nc4 = _nc4.Dataset(cfile)
             except Exception:                              # noqa: BLE001  (e.g. classic file and odd build)
                 self.nc4 = None
         if self.nc4 is None:
-            from scipy.io import netcdf_file
-            self.sp = netcdf_file(cfile, 'r', mmap=False, maskandscale=False)
+            from . import h5lite
+            if h5lite.is_hdf5(cfile):                      # a NetCDF-4 file and no netCDF4 package: the system's libhdf5
+                self.h5 = h5lite.H5File(cfile)
+            else:
+                from scipy.io import netcdf_file
+                self.sp = netcdf_file(cfile, 'r', mmap=False, maskandscale=False)
 
     def has_var(self, name):
+        if self.h5 is not None:                            # a dimension without coordinate variable is a dataset too
+            return self.h5.has(name) and not (self.h5.has_attr(name, 'NAME') and
+                                              str(self.h5.attr(name, 'NAME')).startswith('This is a netCDF dimension but not'))
         return name in (self.nc4.variables if self.nc4 is not None else self.sp.variables)
 
     def has_dim(self, name):
+        if self.h5 is not None:                            # NetCDF-4 stores every dimension as a dataset of its name
+            return self.h5.has(name) and self.h5.has_attr(name, 'CLASS')
         return name in (self.nc4.dimensions if self.nc4 is not None else self.sp.dimensions)
 
     def dim(self, name):
+        if self.h5 is not None:
+            return int(self.h5.shape(name)[0])
         if self.nc4 is not None:
             return self.nc4.dimensions[name].size
         n = self.sp.dimensions[name]
@@ -64,6 +81,8 @@ class _Reader:
         return int(n)
 
     def var(self, name, index=Ellipsis):
+        if self.h5 is not None:
+            return self.h5.read(name, index)               # raw values (no masking, no scale/offset), like the two below
         if self.nc4 is not None:
             v = self.nc4.variables[name]
             v.set_auto_mask(False)                         # raw values: the reference assigns masked slabs into plain arrays
@@ -71,12 +90,14 @@ class _Reader:
         return np.array(self.sp.variables[name][index])
 
     def attr(self, name, att):
+        if self.h5 is not None:
+            return self.h5.attr(name, att)
         v = (self.nc4 if self.nc4 is not None else self.sp).variables[name]
         a = getattr(v, att)
         return a.decode() if isinstance(a, bytes) else a
 
     def close(self):
-        (self.nc4 if self.nc4 is not None else self.sp).close()
+        (self.h5 if self.h5 is not None else self.nc4 if self.nc4 is not None else self.sp).close()
 
     def __enter__(self):
         return self

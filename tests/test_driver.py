@@ -353,3 +353,55 @@ def test_sidfex_seeding_reproduces_the_reference_fixture(tmp_path, monkeypatch, 
             got = np.asarray(f.var(name)).astype(np.float32)[0]
             assert np.array_equal(got, g[key]), name          # float32, bit for bit
         assert f.attr("time", "units") == ncio.tunits_default and f.attr("y_pos", "units") == "km"
+
+
+def test_reference_seeding_file_is_read_without_netcdf4(golden):
+    """The reference's committed seeding file (tools/nc/sitrack_seeding_sidfex_19961215_00_HSS5.nc__KEEP, a NetCDF-4 =
+    HDF5 file with deflate + shuffle; copied here as a data fixture) through this build's readers: netCDF4 is absent,
+    the system's libhdf5 does it (sitrack_amd/h5lite.py).  Values = golden set G7 (decoded independently with h5dump)."""
+    from sitrack_amd import h5lite
+    if ncio.backend() != "netCDF4" and not h5lite.available():
+        pytest.skip("neither netCDF4 nor a loadable libhdf5 here")
+    f = os.path.join(os.path.dirname(__file__), "golden", "sitrack_seeding_sidfex_19961215_00_HSS5.nc")
+    g = golden("g7_projection.npz")
+    idate0, idateN, seed_name, seed_type, _ = ncio.SeedFileTimeInfo(f)
+    assert (idate0, idateN, seed_type) == (850608000, 850608000, 'sidfex') and seed_name == 'sitrack_seeding_sidfex_19961215_00_HSS5'
+    zt, ids, zg, zc = ncio.LoadNCdata(f, krec=0)
+    assert int(zt) == int(g["time"][0]) and np.array_equal(ids, g["id_buoy"]) and ids.dtype == np.int64
+    assert np.array_equal(zc[:, 0].astype('f4'), g["y_pos"]) and np.array_equal(zc[:, 1].astype('f4'), g["x_pos"])
+    assert np.array_equal(zg[:, 0].astype('f4'), g["latitude"])
+    assert np.array_equal(zg[:, 1].astype('f4'), np.mod(g["longitude"].astype('f8'), 360.).astype('f4'))      # ncio.py:303
+    vt = ncio.LoadNCtime(f)
+    assert list(np.atleast_1d(vt[-1] if isinstance(vt, tuple) else vt)) == [850608000]
+    if ncio.backend() != "netCDF4":
+        h = h5lite.H5File(f)
+        assert h.shape("latitude") == (1, 10) and h.read("latitude", (0, slice(2, 5))).tolist() == g["latitude"][2:5].tolist()
+        assert h.attr("time", "units") == ncio.tunits_default and float(h.attr("x_pos", "_FillValue")) == -9999.
+        assert np.array_equal(h.read("x_pos", (Ellipsis,)), h.read("x_pos")) and h.read("id_buoy", -1) == g["id_buoy"][-1]
+        with pytest.raises(KeyError):
+            h.read("no_such_variable")
+        with pytest.raises(IndexError):
+            h.read("latitude", 3)
+        h.close()
+
+
+@pytest.mark.gpu
+def test_cli_with_the_reference_seeding_file(tmp_path, monkeypatch):
+    """`-s` = the reference's own seeding file (NetCDF-4), mesh and SI3 records synthetic (NetCDF-3): whole command
+    against the oracle-driven restatement of the driver."""
+    from sitrack_amd import h5lite
+    if ncio.backend() != "netCDF4" and not h5lite.available():
+        pytest.skip("neither netCDF4 nor a loadable libhdf5 here")
+    monkeypatch.chdir(tmp_path)
+    c = make_case(str(tmp_path), nrec=10, Nj=96, Ni=96, dkm=50.0)
+    f = os.path.join(os.path.dirname(__file__), "golden", "sitrack_seeding_sidfex_19961215_00_HSS5.nc")
+    _, ids, zg, zc = ncio.LoadNCdata(f, krec=0)
+    c["ids"], c["sll"], c["yx"] = ids, zg, zc              # what the driver will read from the file (f4 values)
+    out = drv.main(["-i", c["si3"], "-m", c["mm"], "-s", f, "-N", "TEST4", "-F"])
+    ref = oracle_run(c, False)
+    assert out["nP"] == ref["nP"] >= 5 and np.array_equal(out["IDs"], ref["ids"])
+    assert np.array_equal(out["vJIt"], ref["jiT"]) and np.array_equal(out["iAlive"], ref["alive"])
+    _, ids2, _, yxo, mko = ncio.LoadNCdata(out["files"][0], krec=-1, lmask=True)
+    assert np.array_equal(ids2, ref["ids"]) and np.array_equal(mko, ref["msk"])
+    assert np.array_equal(yxo.astype('f4'), ref["pos"].astype('f4'))
+    assert '_tracking_sidfex_' in out["files"][0] or 'sidfex' in out["files"][0]
