@@ -81,13 +81,22 @@ class _Reader:
         return int(n)
 
     def var(self, name, index=Ellipsis):
-        if self.h5 is not None:
-            return self.h5.read(name, index)               # raw values (no masking, no scale/offset), like the two below
         if self.nc4 is not None:
             v = self.nc4.variables[name]
             v.set_auto_mask(False)                         # raw values: the reference assigns masked slabs into plain arrays
-            return np.array(v[index])
-        return np.array(self.sp.variables[name][index])
+            return np.array(v[index])                      # (netCDF4 still applies scale_factor / add_offset)
+        if self.h5 is not None:
+            a = self.h5.read(name, index)
+            has = lambda att: self.h5.has_attr(name, att)                          # noqa: E731
+        else:
+            v = self.sp.variables[name]
+            a = np.array(v[index])
+            has = lambda att: hasattr(v, att)                                      # noqa: E731
+        if has('scale_factor') or has('add_offset'):       # packed variable: what netCDF4 would hand out
+            sf = self.attr(name, 'scale_factor') if has('scale_factor') else 1.0
+            ao = self.attr(name, 'add_offset') if has('add_offset') else 0.0
+            a = a * sf + ao
+        return a
 
     def attr(self, name, att):
         if self.h5 is not None:

@@ -405,3 +405,15 @@ def test_cli_with_the_reference_seeding_file(tmp_path, monkeypatch):
     assert np.array_equal(ids2, ref["ids"]) and np.array_equal(mko, ref["msk"])
     assert np.array_equal(yxo.astype('f4'), ref["pos"].astype('f4'))
     assert '_tracking_sidfex_' in out["files"][0] or 'sidfex' in out["files"][0]
+
+
+def test_packed_variables_are_unpacked_like_netcdf4_would(tmp_path):
+    """scale_factor / add_offset: netCDF4 (what the reference reads with) applies them on access; the fall-back readers
+    do the same."""
+    fn = str(tmp_path / "packed.nc")
+    raw = np.arange(12, dtype='i2').reshape(3, 4)
+    _write_nc3(fn, {"y": 3, "x": 4}, {"packed": ('i2', ('y', 'x'), raw, {"scale_factor": 0.5, "add_offset": 10.0}),
+                                        "plain": ('i2', ('y', 'x'), raw, None)})
+    with ncio._Reader(fn) as f:
+        assert np.array_equal(f.var("packed"), raw * 0.5 + 10.0) and np.array_equal(f.var("packed", 1), raw[1] * 0.5 + 10.0)
+        assert np.array_equal(f.var("plain"), raw) and f.var("plain").dtype.kind == 'i'
