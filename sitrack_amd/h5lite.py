@@ -232,7 +232,7 @@ class H5File:
                         buf = C.create_string_buffer(sz * n + 1)
                         if self.L.H5Aread(a, tid, buf) < 0:
                             raise OSError("H5Aread(%s.%s) failed" % (name, att))
-                        vals = [buf.raw[k * sz:(k + 1) * sz].split(b"\\0")[0].decode() for k in range(n)]
+                        vals = [buf.raw[k * sz:(k + 1) * sz].split(b"\x00")[0].decode() for k in range(n)]
                     return vals[0] if n == 1 else vals
                 key = self._npkind(tid, name + "." + att)
                 out = np.empty(n, dtype=np.dtype(key))

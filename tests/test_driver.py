@@ -129,9 +129,23 @@ def _write_nc3(fname, dims, variables, attrs=None):
     f.close()
 
 
-def make_case(tmp, nrec=14, nP=300, two_d_time=False, Nj=60, Ni=70, dkm=10.0):
-    """Synthetic NANUK-like inputs as NetCDF-3 files: mesh_mask, icemod (hourly), seeding file."""
+def _write_h5_like_nc3(fname, dims, variables, attrs=None):
+    """same arguments as _write_nc3, written as an HDF5 file laid out like NetCDF-4 (tests/h5write.py)"""
+    import h5write
+    unl = [d for d, n in dims.items() if n is None]
+    vv = {}
+    for name, (typ, dd, data, att) in variables.items():
+        vv[name] = (np.asarray(data).astype(np.dtype(typ).newbyteorder('=')), att, bool(dd) and dd[0] in unl)
+    dl = {d: (n if n is not None else max([np.shape(v[2])[0] for v in variables.values() if v[1] and v[1][0] == d] + [0]))
+          for d, n in dims.items()}
+    h5write.write_h5(fname, vv, dims=dl)
+
+
+def make_case(tmp, nrec=14, nP=300, two_d_time=False, Nj=60, Ni=70, dkm=10.0, fmt="nc3"):
+    """Synthetic NANUK-like inputs: mesh_mask, icemod (hourly), seeding file -- as NetCDF-3 files, or (fmt="hdf5") as
+    HDF5 files laid out like the NetCDF-4 files NEMO and the reference's seeding tools write."""
     from oracle import oracle as orc
+    _write_nc3 = globals()["_write_nc3"] if fmt == "nc3" else _write_h5_like_nc3
     g = syn.make_grid(Nj, Ni, dkm=dkm, warp=1.0)
     for k in ("Yt", "Yu", "Yv", "Yf"):
         g[k] = g[k] - 250.
@@ -164,7 +178,8 @@ def make_case(tmp, nrec=14, nP=300, two_d_time=False, Nj=60, Ni=70, dkm=10.0):
     seed = os.path.join(tmp, "sitrack_seeding_nemoTsi3_19961215_00_HSS5.nc")
     sv = {"time": ('i4', ('time',), np.array([base], dtype='i4'), {"units": ncio.tunits_default}),
           "buoy": ('i4', ('buoy',), np.arange(nP, dtype='i4'), None),
-          "id_buoy": ('f8', ('buoy',), ids.astype(np.float64), {"units": "ID of buoy"}),
+          "id_buoy": (('f8', ('buoy',), ids.astype(np.float64), {"units": "ID of buoy"}) if fmt == "nc3" else
+                      ('i8', ('buoy',), ids, {"units": "ID of buoy"})),
           "latitude": ('f4', ('time', 'buoy'), sll[None, :, 0].astype('f4'), None),
           "longitude": ('f4', ('time', 'buoy'), sll[None, :, 1].astype('f4'), None),
           "y_pos": ('f4', ('time', 'buoy'), yx[None, :, 0].astype('f4'), None),
@@ -417,3 +432,62 @@ def test_packed_variables_are_unpacked_like_netcdf4_would(tmp_path):
     with ncio._Reader(fn) as f:
         assert np.array_equal(f.var("packed"), raw * 0.5 + 10.0) and np.array_equal(f.var("packed", 1), raw[1] * 0.5 + 10.0)
         assert np.array_equal(f.var("plain"), raw) and f.var("plain").dtype.kind == 'i'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("two_d_time", [False, True])
+def test_cli_on_hdf5_inputs(tmp_path, monkeypatch, two_d_time):
+    """mesh_mask, SI3 records and seeding file as HDF5 files laid out like NetCDF-4 (chunked, shuffle + deflate,
+    unlimited time axis, int64 ids), no netCDF4 package: read through libhdf5 (whole variables, single records and the
+    row bands of records as hyperslabs).  Same results as the oracle-driven driver, and as the same case from NetCDF-3."""
+    from sitrack_amd import h5lite
+    if ncio.backend() == "netCDF4" or not h5lite.available():
+        pytest.skip("exercises the libhdf5 reader (needs libhdf5 and no netCDF4)")
+    (tmp_path / "h5").mkdir(); (tmp_path / "n3").mkdir()
+    c = make_case(str(tmp_path / "h5"), two_d_time=two_d_time, fmt="hdf5")
+    assert h5lite.is_hdf5(c["si3"]) and h5lite.is_hdf5(c["mm"]) and h5lite.is_hdf5(c["seed"])
+    argv = lambda cc: ["-i", cc["si3"], "-m", cc["mm"], "-s", cc["seed"], "-N", "TEST4"] + ([] if two_d_time else ["-F"])   # noqa: E731
+    monkeypatch.chdir(tmp_path / "h5")
+    out = drv.main(argv(c))
+    ref = oracle_run(c, two_d_time)
+    assert out["nP"] == ref["nP"] and np.array_equal(out["IDs"], ref["ids"])
+    assert np.array_equal(out["vJIt"], ref["jiT"]) and np.array_equal(out["iAlive"], ref["alive"])
+    c3 = make_case(str(tmp_path / "n3"), two_d_time=two_d_time)
+    monkeypatch.chdir(tmp_path / "n3")
+    out3 = drv.main(argv(c3))
+    assert out3["files"] == out["files"]
+    for f in out["files"]:
+        a = ncio.LoadNCdata(str(tmp_path / "h5" / f), krec=-1, lmask=True)
+        b = ncio.LoadNCdata(str(tmp_path / "n3" / f), krec=-1, lmask=True)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+
+
+def test_hdf5_reader_on_netcdf4_like_layout(tmp_path):
+    """chunked + shuffle + deflate datasets with an unlimited leading dimension, NUL-terminated fixed-length string
+    attributes, dimension-only datasets: whole reads, single records, row bands (hyperslabs), negative indices."""
+    from sitrack_amd import h5lite
+    if not h5lite.available():
+        pytest.skip("no loadable libhdf5 here")
+    import h5write
+    rng = np.random.default_rng(0)
+    u = rng.standard_normal((6, 33, 41)).astype('f4')
+    tc = (850608000 + 1800 + 3600 * np.arange(6)).astype('f8')
+    fn = str(tmp_path / "like_nc4.nc")
+    h5write.write_h5(fn, {"time_counter": (tc, {"units": ncio.tunits_default}, True),
+                          "u_ice": (u, {"units": "m/s", "_FillValue": np.float32(1e20)}, True),
+                          "tmask": (np.ones((1, 1, 33, 41), 'i1'), None, False)}, dims={"time_counter": 6, "y": 33, "x": 41})
+    assert h5lite.is_hdf5(fn)
+    if ncio.backend() == "netCDF4":
+        pytest.skip("netCDF4 is installed: the libhdf5 path is not the one ncio takes")
+    with ncio._Reader(fn) as r:
+        assert r.has_dim("time_counter") and r.has_dim("y") and not r.has_var("y") and r.has_var("u_ice") and not r.has_var("nope")
+        assert r.dim("time_counter") == 6 and r.dim("x") == 41
+        assert r.attr("time_counter", "units") == ncio.tunits_default and r.attr("u_ice", "units") == "m/s"
+        assert np.float32(r.attr("u_ice", "_FillValue")) == np.float32(1e20)
+        assert np.array_equal(r.var("u_ice"), u) and np.array_equal(r.var("u_ice", 3), u[3]) and np.array_equal(r.var("u_ice", -1), u[-1])
+        assert np.array_equal(r.var("u_ice", (2, slice(5, 9))), u[2, 5:9]) and np.array_equal(r.var("u_ice", (slice(1, 4),)), u[1:4])
+        assert np.array_equal(r.var("u_ice", (4, slice(0, 0))), u[4, 0:0]) and r.var("tmask", (0, 0)).shape == (33, 41)
+        assert np.array_equal(r.var("u_ice", np.array([0, 5])), u[[0, 5]])            # fancy index: read all, then numpy
+    nrec, vt = ncio.ModelFileTimeInfo(fn)[:2]
+    assert nrec == 6 and np.array_equal(vt, tc.astype('i4'))
