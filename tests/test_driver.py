@@ -473,7 +473,7 @@ def test_hdf5_reader_on_netcdf4_like_layout(tmp_path):
     rng = np.random.default_rng(0)
     u = rng.standard_normal((6, 33, 41)).astype('f4')
     tc = (850608000 + 1800 + 3600 * np.arange(6)).astype('f8')
-    fn = str(tmp_path / "like_nc4.nc")
+    fn = str(tmp_path / "TEST4-EXP01_1h_19961215_19961216_icemod.nc")      # ModelFileTimeInfo parses the NAME
     h5write.write_h5(fn, {"time_counter": (tc, {"units": ncio.tunits_default}, True),
                           "u_ice": (u, {"units": "m/s", "_FillValue": np.float32(1e20)}, True),
                           "tmask": (np.ones((1, 1, 33, 41), 'i1'), None, False)}, dims={"time_counter": 6, "y": 33, "x": 41})
