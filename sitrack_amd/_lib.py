@@ -83,6 +83,30 @@ def build(force=False, verbose=False):
 _lib = None
 
 
+def _one_hip_runtime():
+    """A process must run on ONE HIP runtime.  PyTorch-ROCm wheels bundle their own (same soname as /opt/rocm's), and
+    whichever copy is loaded first serves both libsitrk.so and torch: with the system's copy first, torch's bundled
+    RCCL/HSA libraries come up next to it and the runtime that initialises second sees no device.  So if PyTorch is
+    installed and not loaded yet, its copy is loaded before libsitrk.so (found without importing torch;
+    SITRK_HIP_RUNTIME=system keeps the system's)."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("SITRK_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    for loc in (spec.submodule_search_locations or []) if spec else []:
+        p = os.path.join(loc, "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            try:
+                C.CDLL(p, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+            return
+
+
 def lib():
     """Load the in-tree extension; raise loudly if it is not there."""
     global _lib
@@ -90,6 +114,7 @@ def lib():
         if not os.path.exists(SO_PATH):
             raise SitrkError("%s not found: build it with `make -C %s` (or __graft_entry__.build()); "
                              "sitrack_amd has no CPU fallback" % (SO_PATH, CSRC))
+        _one_hip_runtime()
         L = C.CDLL(SO_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
