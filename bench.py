@@ -54,14 +54,14 @@ def parse():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--buoys", type=int, default=0, help="override the configuration's buoys per GPU (capacity runs; not the metric's workload)")
-    ap.add_argument("--records", type=int, default=8, help="device-resident records cycled")
+    ap.add_argument("--records", type=int, default=32, help="device-resident records, cycled (32 x 201 MB at 4096^2)")
     ap.add_argument("--resort", type=int, default=-1, help="re-sort buoys by cell every R steps (0 never, -1 default)")
     ap.add_argument("--uv-strategy", type=int, default=1)
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--check", action="store_true", help="verify a subsample against the oracle after the run")
-    ap.add_argument("--fuse", type=int, default=8,
+    ap.add_argument("--fuse", type=int, default=32,
                     help="resident records advanced per launch by sitrk_run (loop interchange; 1 = one launch per record)")
     ap.add_argument("--e2e-full", action="store_true", help="e2e regime: upload whole records instead of the row band the buoys can touch")
     ap.add_argument("--regime", default="resident", choices=["resident", "e2e"],
@@ -208,7 +208,7 @@ def main():
 
     per_record = None
     if a.regime == "resident":
-        fuse = max(1, min(a.fuse, K, 8))
+        fuse = max(1, min(a.fuse, K, 32))               # a launch advances distinct resident records only
         ctx.set_tuning(fuse=fuse)
         ctx.run(0, 0, a.warmup)
         barrier()

@@ -210,7 +210,7 @@ SITRK_API int sitrk_set_tuning(sitrk_t *h, const char *knob, int value)
         h->step_block = value;
         return SITRK_OK;
     }
-    else if (!strcmp(knob, "fuse")) {                // records per launch in sitrk_run (1..8)
+    else if (!strcmp(knob, "fuse")) {                // records per launch in sitrk_run (1..32)
         if (value < 1 || value > kMaxFuse) return fail(h, SITRK_EINVAL, "sitrk_set_tuning: fuse must be 1..%d", kMaxFuse);
         h->fuse = value;
         return SITRK_OK;
@@ -577,7 +577,7 @@ SITRK_API int sitrk_run(sitrk_t *h, int slot0, int jrec0, int nsteps)
     NEED(slot0 >= 0 && slot0 < h->nslots, "sitrk_run: slot0 out of range");
     NEED(h->st[0].pos, "sitrk_run: call sitrk_set_buoys first");
     if (h->nP == 0) return SITRK_OK;
-    const int fuse = std::max(1, std::min(std::min(h->fuse, kMaxFuse), h->nslots));
+    const int fuse = std::max(1, std::min(std::min(h->fuse, kMaxFuse), h->nslots));    // a launch never wraps the slot ring
     const size_t n = (size_t)h->Nj * h->Ni, es = elem_size(h->dtype);
     int k = 0;
     while (k < nsteps) {

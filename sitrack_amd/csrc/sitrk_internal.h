@@ -47,7 +47,7 @@ struct sitrk_ctx {
     // non-temporal state streams -2 %, tile-major 8x16 cell order -8 %, XCD-chunked block order +5 % (off)
     int tune = sitrk::TUNE_NT_STATE;    // TUNE_* bits
     int step_block = 512;               // workgroup size of advect_step_kernel (512: -3.6 % vs 256, 1024: +1.8 %)
-    int fuse = 8;                       // sitrk_run: consecutive resident records advanced per launch (1 = one launch per record); -28 % per step at 8
+    int fuse = 32;                      // sitrk_run: consecutive resident records advanced per launch, <= nslots (1 = one launch per record)
     int tile_j = 8, tile_i = 16;        // sort order: 0 = row-major cells, else tile-major tiles of tile_j x tile_i cells
 
     // records

@@ -6,7 +6,7 @@
 // slabs; L1/L2 coalesce them, there is no cross-lane reuse left for LDS to exploit, and nothing is a
 // contraction (no MFMA).  Two launch forms:
 //   advect_step_kernel : one record per launch  -- HBM bound (~84 B and ~250 fp64-issue slots per particle-step)
-//   advect_run_kernel  : up to 8 resident records per launch, buoy and cell context in registers -- fp64-issue bound
+//   advect_run_kernel  : up to 32 resident records per launch, buoy and cell context in registers -- issue bound
 // Measurements and the optimisation history are in DESIGN.md section 3.2.
 #pragma once
 #include "sitrk_internal.h"
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(BLOCK, 8) void advect_step_kernel(StepArgs a)
 // record), and the once-per-record position/cell streams are read and written once per launch.
 // Per buoy the sequence of operations is exactly the one of advect_step_kernel -> identical results.
 // ---------------------------------------------------------------------------
-static constexpr int kMaxFuse = 8;
+static constexpr int kMaxFuse = 32;
 
 struct RunArgs {
     StepArgs s;                         // s.u/s.v/s.kill unused; s.jrec = first record

@@ -24,7 +24,7 @@ def one_case(rng, idx, nstrat=2):
     Nj, Ni = int(rng.integers(24, 260)), int(rng.integers(24, 300))
     warp = float(rng.choice([0.0, 0.5, 1.0]))
     dkm = float(rng.choice([1.0, 4.0, 12.5]))
-    K = int(rng.integers(1, 9))
+    K = int(rng.integers(1, 9)) if rng.random() < 0.8 else int(rng.integers(9, 41))      # up to 40 resident records
     nP = int(rng.integers(1, 40000))
     Nt = int(rng.integers(1, 60))
     strat = int(rng.integers(0, nstrat))       # 0/1 = the reference's rules; 2 = the linear-interpolation extra
@@ -55,7 +55,7 @@ def one_case(rng, idx, nstrat=2):
     first = last = None
     if windowed:
         first = rng.integers(0, max(1, Nt // 2), n); last = first + rng.integers(-2, Nt, n)
-    fuse = int(rng.choice([1, 2, 8]))
+    fuse = int(rng.choice([1, 2, 8, 32]))
     tile = int(rng.choice([0, 8 * 256 + 16, 4 * 256 + 4, 32 * 256 + 32]))
     trk.ctx.set_tuning(fuse=fuse, sort_tile=tile, nt_state=int(rng.integers(0, 2)), xcd_remap=int(rng.integers(0, 2)),
                        step_block=int(rng.choice([256, 512, 1024])))

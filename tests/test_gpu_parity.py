@@ -141,14 +141,14 @@ def test_random_cloud_vs_oracle(warp, field_dtype):
 def test_fused_run_equals_stepping(windowed):
     """sitrk_run with several records per launch == one launch per record == the oracle."""
     grid = syn.make_grid(120, 128, dkm=4.0, warp=1.0)
-    K, Nt = 7, 37
+    K, Nt = 35, 81
     u, v, sic = syn.make_fields(grid, K=K, seed=13, umax=0.9, drift=0.3, ripple=0.1)
     tmask = grid["tmask"].copy(); tmask[50:56, 60:70] = 0
     sic[:, 20:30, 20:50] = 0.02
     _, yx = syn.make_buoys(grid, 20000, seed=4, frac=0.75)
     rng = np.random.default_rng(1)
     res = []
-    for fuse in (1, 3, 8):
+    for fuse in (1, 3, 8, 32):
         trk = make_tracker(grid, tmask, K)
         found, ji, _ = sit.FindContainingCell(yx, syn.nearest_t_plane(grid, yx), ctx=trk.ctx)
         n = int(found.sum())
