@@ -230,6 +230,17 @@ def main():
             barrier()
             per_record = (time.perf_counter() - t1, ev1_ms)
             ctx.set_tuning(fuse=fuse)
+        eight = None
+        if fuse > 8:
+            # for reference: 8 records per launch (the K = 8 of SURVEY 8d's synthetic set-up allows no more)
+            ctx.set_tuning(fuse=8)
+            s2 = a.warmup + 2 * a.steps
+            barrier()
+            t2 = time.perf_counter()
+            ctx.run(s2 % K, s2, a.steps)
+            barrier()
+            eight = time.perf_counter() - t2
+            ctx.set_tuning(fuse=fuse)
     else:
         fuse = 1
         # end-to-end: record s goes pinned host -> slot s%2 on a copy stream (rank 0), is broadcast, and is
@@ -305,7 +316,7 @@ def main():
         nalive = int(t[0])
 
     if a.check and rank == 0:
-        nchk = (a.warmup + a.steps) if per_record is None else (a.warmup + 2 * a.steps)
+        nchk = a.warmup + a.steps * (1 + (per_record is not None) + (a.regime == "resident" and eight is not None))
         cpu_baseline_check(ctx, grid, u, v, sic, yx, ji, nchk, a.uv_strategy)
 
     if rank == 0:
@@ -368,6 +379,9 @@ def main():
                 "roofline": {"bound": "hbm", "achieved": A1 / s1 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": A1 / s1 / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": A1,
                              "avg_launch_ms": 1e3 * s1}}
+        if a.regime == "resident" and eight is not None:
+            line["eight_records_per_launch"] = {"value": total / eight, "ms_per_step": 1e3 * eight / a.steps,
+                                                "note": "same kernel, 8 records per launch (SURVEY 8d keeps K = 8 records resident)"}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(grid, u, v, sic, yx, ji, a.cpu_seconds, a.uv_strategy)
         print(json.dumps(line))
