@@ -4,13 +4,14 @@
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one model record applied to every buoy of the batch.  By default
-`sitrk_run` advances 8 resident records per launch (advect_run_kernel: loop
+`sitrk_run` advances 32 resident records per launch (advect_run_kernel: loop
 interchange, every buoy still takes every step; `--fuse 1` = one launch of
 advect_step_kernel per record, also timed in the same run and reported under
 `per_record_launch`).  Workload at N=1 = BASELINE.json configs[2] (C3,
 the one the metric is quoted on): synthetic regular 4096x4096 C-grid (4 km),
-1e7 random buoys in the central 60 %, 8 device-resident fp32 records (solid-body
-rotation + per-record drift) cycled.  N>1: one process per GPU,
+1e7 random buoys in the central 60 %, 32 device-resident fp32 records (solid-body
+rotation + per-record drift; the survey keeps 8 resident -- the same
+kernel at 8 records per launch is reported under `eight_records_per_launch`) cycled.  N>1: one process per GPU,
 each rank owns a contiguous range of 1e7 buoys of the N*1e7 set (weak scaling),
 the record slabs are generated on rank 0 and broadcast over RCCL into every
 rank's resident slots (the path's only exchange step); stepping needs no
