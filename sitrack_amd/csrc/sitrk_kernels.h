@@ -391,15 +391,20 @@ __global__ __launch_bounds__(kBlock, 5) void advect_run_kernel(RunArgs ra)
     bool moved = false;
     CellCtx x;
     load_ctx<sizeof(FT)>(a, c, x);
+    // the record pointers (scalar loads from the kernel arguments) are fetched one record ahead: a record's vector
+    // loads go out at the top of its iteration instead of behind a scalar load and its wait (-0.7 %)
+    const char *ub_next = (const char *)ra.u[0], *vb_next = (const char *)ra.v[0];
 #pragma unroll 1
     for (int r = 0; r < ra.nrec; r++) {
         const int jrec = a.jrec + r;
+        const char *ub = ub_next, *vb = vb_next;
+        const int rn = (r + 1 < ra.nrec) ? r + 1 : r;
+        ub_next = (const char *)ra.u[rn]; vb_next = (const char *)ra.v[rn];
         if (WINDOW) {
             if (jrec < first) continue;
             if (jrec > last) break;
         }
         // the four velocity candidates u[jT,iT-1], u[jT,iT], v[jT-1,iT], v[jT,iT]
-        const char *ub = (const char *)ra.u[r], *vb = (const char *)ra.v[r];
         FT fu0 = *(const FT *)(ub + x.o1 - sizeof(FT)), fu1 = *(const FT *)(ub + x.o1);
         FT fv0 = *(const FT *)(vb + x.o0), fv1 = *(const FT *)(vb + x.o1);
         double zU, zV;
