@@ -116,8 +116,10 @@ def record_windows(zTpos, ztime_model, kstrt, kstop, iTmA, iTmB, nP):
     zLst = np.zeros(nP, dtype=int) + kstop
     half = int(rdt / 2)
     tm = np.asarray(ztime_model)
-    late = np.where(zTpos[0, :] >= iTmA + half)[0]
-    early = np.where(zTpos[1, :] < iTmB - half)[0]
+    # (entries the seeding file holds as _FillValue arrive masked, like netCDF4 hands them to the reference: a masked
+    # comparison is no match for np.where, so such a buoy keeps the full window)
+    late = np.where(np.ma.filled(zTpos[0, :] >= iTmA + half, False))[0]
+    early = np.where(np.ma.filled(zTpos[1, :] < iTmB - half, False))[0]
     if tm.ndim == 1 and (tm.size < 2 or np.all(np.diff(tm) > 0)):
         if late.size:
             cnt = np.searchsorted(tm + half, zTpos[0, late], side='left')        # how many tm+half < T
@@ -214,7 +216,7 @@ def main(argv=None):
     z1stModelRec = np.zeros(nP, dtype=int) + kstrt
     zLstModelRec = np.zeros(nP, dtype=int) + kstop
     if lUse2DTime:
-        zTpos = np.asarray(zTpos)
+        zTpos = zTpos if np.ma.isMaskedArray(zTpos) else np.asarray(zTpos)
         if zTpos.shape != (2, nP) and zTpos.ndim == 2 and zTpos.shape[1] > nP and len(idxK) == nP:
             # SeedInit cancelled buoys: keep the time positions of the survivors.  (The reference has this line
             # commented out, si3_part_tracker.py:250, and then stops on the shape check of :269-272.)

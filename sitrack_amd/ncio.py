@@ -98,6 +98,27 @@ class _Reader:
             a = a * sf + ao
         return a
 
+    def has_attr(self, name, att):
+        if self.h5 is not None:
+            return self.h5.has_attr(name, att)
+        return hasattr((self.nc4 if self.nc4 is not None else self.sp).variables[name], att)
+
+    def fill_of(self, name):
+        """the variable's _FillValue, or None"""
+        return self.attr(name, '_FillValue') if self.has_attr(name, '_FillValue') else None
+
+    def var_masked(self, name, index=Ellipsis):
+        """What netCDF4's default auto-masking hands out for seeding / trajectory files (the reference reads them with
+        it, ncio.py:199-326): entries equal to `_FillValue` come back masked, so that `np.min`/`np.max` skip them.
+        Model fields (u_ice, v_ice, siconc, mesh) are read raw with var(): the reference assigns those slabs into plain
+        arrays, fill data included (si3_part_tracker.py:372-374)."""
+        a = self.var(name, index)
+        fv = self.fill_of(name)
+        if fv is None:
+            return a
+        hit = (a == np.asarray(fv).astype(a.dtype))
+        return np.ma.masked_array(a, mask=hit) if np.any(hit) else a
+
     def attr(self, name, att):
         if self.h5 is not None:
             return self.h5.attr(name, att)
@@ -120,6 +141,18 @@ def _project(ctx, lat, lon):
     return ConvertGeo2CartesianNPSkm(lat, lon, 70., -45., ctx=ctx)
 
 
+def _lon360(zlon, fill=None):
+    """`np.mod(zlon, 360.)` evaluated in the variable's STORED dtype like the reference (ncio.py:50-51,86-87,303: the
+    file-dtype array is passed to np.mod and, for seeding files, assigned back into it), and only then promoted to
+    float64 -- for a negative float32 longitude the two orders differ by up to ~1.5e-5 degrees.  Entries equal to
+    `fill` (netCDF4 would hand them out masked, and np.mod leaves masked entries alone) keep their raw value."""
+    z = np.asarray(zlon)
+    m = np.mod(z, z.dtype.type(360.)) if z.dtype.kind == 'f' else np.mod(z, 360.)
+    if fill is not None:
+        m = np.where(z == z.dtype.type(fill), z, m)
+    return np.asarray(m, dtype=np.float64)
+
+
 def _ctx_or_default(ctx):
     if ctx is not None:
         return ctx
@@ -140,8 +173,7 @@ def GetModelGrid(fNCmeshmask, alsoF=False, ctx=None):
         ze2T = f.var('e2t', 0) / 1000.
     kmaskt = np.array(kmaskt, dtype='i1')
     zlatT = np.asarray(zlatT, dtype=np.float64); zlatF = np.asarray(zlatF, dtype=np.float64)
-    zlonT = np.mod(np.asarray(zlonT, dtype=np.float64), 360.)
-    zlonF = np.mod(np.asarray(zlonF, dtype=np.float64), 360.)
+    zlonT, zlonF = _lon360(zlonT), _lon360(zlonF)
     zYt, zXt = _project(ctx, zlatT, zlonT)
     zYf, zXf = _project(ctx, zlatF, zlonF)
     zResKM = np.sqrt(ze1T * ze1T + ze2T * ze2T).astype(np.float64)
@@ -156,8 +188,8 @@ def GetModelUVGrid(fNCmeshmask, ctx=None):
     with _Reader(fNCmeshmask) as f:
         zlonV = f.var('glamv', 0); zlatV = f.var('gphiv', 0)
         zlonU = f.var('glamu', 0); zlatU = f.var('gphiu', 0)
-    zYv, zXv = _project(ctx, np.asarray(zlatV, dtype=np.float64), np.mod(np.asarray(zlonV, dtype=np.float64), 360.))
-    zYu, zXu = _project(ctx, np.asarray(zlatU, dtype=np.float64), np.mod(np.asarray(zlonU, dtype=np.float64), 360.))
+    zYv, zXv = _project(ctx, np.asarray(zlatV, dtype=np.float64), _lon360(zlonV))
+    zYu, zXu = _project(ctx, np.asarray(zlatU, dtype=np.float64), _lon360(zlonU))
     return zYv, zXv, zYu, zXu
 
 
@@ -169,13 +201,13 @@ def LoadNCtime(cfile, ltime2d=False):
         Nt = f.dim('time')
         if f.attr('time', 'units') != tunits_default:
             raise ValueError(' ERROR [LoadNCtime()]: we expect "' + tunits_default + '" as units for the time record vector')
-        ztime = f.var('time')
+        ztime = f.var_masked('time')
         if ltime2d:
             if not f.has_var('time_pos'):
                 raise ValueError(' ERROR [LoadNCtime()]: no variable `time_pos` found into input file!')
             if f.attr('time_pos', 'units') != tunits_default:
                 raise ValueError(' ERROR [LoadNCtime()]: wrong units for the 2D time record array')
-            ztime2d = f.var('time_pos')
+            ztime2d = f.var_masked('time_pos')
             if ztime2d.shape[0] != Nt:
                 raise ValueError(' ERROR [LoadNCtime()]: array `time_pos` has not the same number of records as `time`!')
             return Nt, ztime, ztime2d
@@ -201,7 +233,7 @@ def LoadNCdata(cfile, krec=-1, lmask=False, lGetTimePos=False):
         kBIDs = np.zeros(nP, dtype=np.int64)
         kBIDs[:] = f.var('id_buoy')
         zlat = np.asarray(f.var('latitude', idxR), dtype=np.float64)
-        zlon = np.mod(np.asarray(f.var('longitude', idxR), dtype=np.float64), 360.)
+        zlon = _lon360(f.var('longitude', idxR), fill=f.fill_of('longitude'))     # (:303) masked entries are left alone
         zy = np.asarray(f.var('y_pos', idxR), dtype=np.float64)
         zx = np.asarray(f.var('x_pos', idxR), dtype=np.float64)
         zmsk = f.var('mask', idxR) if lmask else None

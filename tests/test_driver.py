@@ -65,6 +65,28 @@ def test_record_windows():
     assert len(np.unique(fast[0])) > 10 and len(np.unique(fast[1])) > 10
 
 
+def test_longitudes_wrap_in_the_stored_dtype():
+    """np.mod(lon, 360.) on the float32 the file holds, THEN float64 (reference ncio.py:50-51,86-87,303); the other order
+    differs by up to ~1.5e-5 degrees for negative longitudes."""
+    rng = np.random.default_rng(11)
+    lon4 = rng.uniform(-180, 0, 20000).astype('f4')
+    got = ncio._lon360(lon4)
+    assert got.dtype == np.float64 and np.array_equal(got, np.mod(lon4, np.float32(360.)).astype('f8'))
+    other = np.mod(lon4.astype('f8'), 360.)
+    assert (got != other).any() and np.abs(got - other).max() < 2e-5
+    lon8 = rng.uniform(-180, 360, 1000)
+    assert np.array_equal(ncio._lon360(lon8), np.mod(lon8, 360.))
+    assert np.array_equal(ncio._lon360(np.array([-9999., -10.], dtype='f4'), fill=-9999.), [-9999., 350.])
+
+
+def test_record_windows_skip_masked_time_positions():
+    base = 850608000
+    vt = (base + 1800 + 3600 * np.arange(24)).astype('i4')
+    zT = np.ma.masked_equal(np.array([[base, -9999, base + 5 * 3600], [vt[-1] + 1800, base + 12 * 3600, -9999]]), -9999)
+    z1, zL = drv.record_windows(zT, vt, 0, 23, vt[0], vt[23], 3)
+    assert list(z1) == [0, 0, 4] and list(zL) == [23, 12, 23]
+
+
 def test_ncio_schema_and_roundtrip_both_backends(tmp_path, monkeypatch):
     """ncSaveCloudBuoys / LoadNCdata / LoadNCtime / *TimeInfo with the NetCDF-3 fall-back and with the netCDF4 code path
     (driven through a minimal stand-in for the absent package: tests/fakes/netCDF4.py)."""
@@ -89,12 +111,16 @@ def test_ncio_schema_and_roundtrip_both_backends(tmp_path, monkeypatch):
         assert np.array_equal(tt, t) and np.array_equal(bid, ids) and np.array_equal(mk, msk) and np.array_equal(tpos, tp)
         assert np.array_equal(yx[..., 0], Y.astype('f4').astype('f8')) and np.array_equal(yx[..., 1], X.astype('f4').astype('f8'))
         assert np.array_equal(ll[..., 0], La.astype('f4').astype('f8'))
-        assert np.array_equal(ll[..., 1], np.mod(Lo.astype('f4').astype('f8'), 360.))          # reference ncio.py:303
+        # reference ncio.py:303: np.mod on the file-dtype (f4) array, assigned back into it; masked (_FillValue) entries untouched
+        lo4 = Lo.astype('f4')
+        want = np.where(lo4 == np.float32(-9999.), lo4, np.mod(lo4, np.float32(360.))).astype('f8')
+        assert np.array_equal(ll[..., 1], want) and want[2, 3] == -9999.
         t1, b1, ll1, yx1 = ncio.LoadNCdata(f, krec=1)
         assert int(t1) == t[1] and yx1.shape == (Nb, 2) and np.array_equal(yx1, yx[1])
         assert ncio.LoadNCtime(f)[0] == Nt
         i0, iN, name, batch, t2d = ncio.SeedFileTimeInfo(f, ltime2d=True)
-        assert (i0, iN) == (-3600 * 3, 850615200) or i0 <= 850608000      # FillValue entries drag the minimum down, as in the reference
+        assert (i0, iN) == (850608000, 850615200)      # the _FillValue entry of time_pos is masked (netCDF4 auto-mask), not a date
+        assert np.ma.isMaskedArray(t2d) and t2d.mask[2, 3] and t2d.mask.sum() == 1
         assert batch == "Y"
         with ncio._Reader(f) as r:
             assert r.attr("time", "units") == ncio.tunits_default and r.attr("longitude", "units") == "degrees south"
@@ -208,7 +234,8 @@ def oracle_run(c, two_d_time, rdt=3600., nthreads=1):
         grid["Y" + k] = np.ascontiguousarray(yx[:, 0].reshape(Nj, Ni)); grid["X" + k] = np.ascontiguousarray(yx[:, 1].reshape(Nj, Ni))
     grid["tmask"] = c["tmask"]
     latT = c["ll"]["t"][:, 0].reshape(Nj, Ni); lonT = np.mod(c["ll"]["t"][:, 1], 360.).reshape(Nj, Ni)
-    pSG = np.stack([c["sll"][:, 0].astype('f4').astype('f8'), np.mod(c["sll"][:, 1].astype('f4').astype('f8'), 360.)], axis=1)
+    pSG = np.stack([c["sll"][:, 0].astype('f4').astype('f8'),
+                    np.mod(c["sll"][:, 1].astype('f4'), np.float32(360.)).astype('f8')], axis=1)      # reference ncio.py:303: mod on the f4
     pSC = c["yx"].astype('f4').astype('f8')
     res = np.full((Nj, Ni), np.sqrt(2.) * c.get("dkm", 10.0))
     tc = c["tc"]
@@ -385,7 +412,7 @@ def test_reference_seeding_file_is_read_without_netcdf4(golden):
     assert int(zt) == int(g["time"][0]) and np.array_equal(ids, g["id_buoy"]) and ids.dtype == np.int64
     assert np.array_equal(zc[:, 0].astype('f4'), g["y_pos"]) and np.array_equal(zc[:, 1].astype('f4'), g["x_pos"])
     assert np.array_equal(zg[:, 0].astype('f4'), g["latitude"])
-    assert np.array_equal(zg[:, 1].astype('f4'), np.mod(g["longitude"].astype('f8'), 360.).astype('f4'))      # ncio.py:303
+    assert np.array_equal(zg[:, 1], np.mod(g["longitude"], np.float32(360.)).astype('f8'))      # ncio.py:303, in the file's f4
     vt = ncio.LoadNCtime(f)
     assert list(np.atleast_1d(vt[-1] if isinstance(vt, tuple) else vt)) == [850608000]
     if ncio.backend() != "netCDF4":

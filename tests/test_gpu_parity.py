@@ -562,6 +562,18 @@ def test_projection(golden, ctx):
     assert np.allclose(back, pts[:-1], rtol=1e-11, atol=1e-8)
 
 
+def test_inverse_projection_pinned_by_the_reference_fixture(golden, ctx):
+    """a12 on the device, direct pin against reference-held data: cart2geo(fixture y_pos, x_pos) == fixture latitude,
+    longitude (lon mod 360) at north_star's 1e-5 relative, all 10 buoys of tools/nc/...HSS5.nc__KEEP."""
+    g = golden("g7_projection.npz")
+    yx = np.stack([g["y_pos"].astype(np.float64), g["x_pos"].astype(np.float64)], axis=1)
+    ll = sit.CartNPSkm2Geo1D(yx, ctx=ctx)
+    assert np.allclose(ll[:, 0], g["latitude"].astype(np.float64), rtol=1e-5, atol=0)
+    assert np.allclose(np.mod(ll[:, 1], 360.), np.mod(g["longitude"].astype(np.float64), 360.), rtol=1e-5, atol=0)
+    # and through the path the driver uses at output records (sitrk_fetch_record's latlon, si3_part_tracker.py:493)
+    assert np.allclose(ll, orc.CartNPSkm2Geo1D(yx), rtol=1e-12, atol=1e-10)
+
+
 def test_record_latlon_of_dead_and_live(ctx):
     grid = syn.make_grid(32, 32, dkm=4.0)
     u, v, sic = syn.make_fields(grid, K=1, umax=0.3)

@@ -168,6 +168,21 @@ def test_g7_inverse_projection_round_trip(golden):
     assert np.all(np.isfinite(dead)) and -180 <= dead[0, 1] <= 180
 
 
+def test_g7_inverse_projection_pinned_by_the_reference_fixture(golden):
+    """a12, direct pin: the reference's own seeding file holds (latitude, longitude) AND the (y_pos, x_pos) its cartopy
+    projection made of them (tools/nc/sitrack_seeding_sidfex_19961215_00_HSS5.nc__KEEP, all f4).  Feeding the stored
+    y_pos/x_pos to the inverse (sitrack/util.py:413-429) must give back the stored latitude/longitude at north_star's
+    tolerance, 1e-5 relative -- reference-held data on both sides, no round trip through our own forward."""
+    g = golden("g7_projection.npz")
+    yx = np.stack([g["y_pos"].astype(np.float64), g["x_pos"].astype(np.float64)], axis=1)
+    ll = orc.CartNPSkm2Geo1D(yx)
+    assert ll.shape == (10, 2)
+    assert np.allclose(ll[:, 0], g["latitude"].astype(np.float64), rtol=1e-5, atol=0)
+    assert np.allclose(np.mod(ll[:, 1], 360.), np.mod(g["longitude"].astype(np.float64), 360.), rtol=1e-5, atol=0)
+    # what the fixture allows to state: the error is that of the f4 storage, far below the bar
+    assert np.abs(ll[:, 0] - g["latitude"]).max() < 2e-5 and np.abs(ll[:, 1] - g["longitude"]).max() < 2e-4
+
+
 def test_g8_get_time_span(golden):
     g = golden("g8_timespan.npz")
     vt = g["vtime"]
