@@ -41,10 +41,17 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured achievable
 
+VALU_PEAK_GINST = 1024 * 2.4 / 4.0   # 256 CUs x 4 SIMDs, 2.4 GHz max clock, one wave64 VALU instruction per 4 cycles per SIMD
+                                     # (the rate SQ_ACTIVE_INST_VALU counts in; MI355X_MICROARCH.md, cycle constants) = 614.4 G/s
+
 CONFIGS = {
     # name: (Nj, Ni, buoys per GPU, label)
     "c3": (4096, 4096, 10_000_000, "C3: synthetic 4096x4096 C-grid, 1e7 buoys/GPU, fp32 records"),
     "c2": (512, 512, 100_000, "C2: synthetic 512x512 C-grid, 1e5 buoys/GPU, fp32 records"),
+    # BASELINE.json configs[3]: 1e8 buoys over 8 GPUs = 1.25e7 per rank.  Selected when --gpus > 1 (weak scaling: the
+    # per-rank shard is C4's at every N, the total is C4's 1e8 at N = 8)
+    "c4": (4096, 4096, 12_500_000, "C4: synthetic 4096x4096 C-grid, 1.25e7 buoys/GPU (1e8 over 8 GPUs), fp32 records, "
+                                   "buoy-range partition + RCCL record broadcast"),
 }
 
 
@@ -53,7 +60,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="auto", choices=["auto"] + sorted(CONFIGS),
+                    help="auto = C3 (the headline configuration) on one GPU, C4's per-rank shard on several")
     ap.add_argument("--buoys", type=int, default=0, help="override the configuration's buoys per GPU (capacity runs; not the metric's workload)")
     ap.add_argument("--records", type=int, default=32, help="device-resident records, cycled (32 x 201 MB at 4096^2)")
     ap.add_argument("--resort", type=int, default=-1, help="re-sort buoys by cell every R steps (0 never, -1 default)")
@@ -65,6 +73,11 @@ def parse():
     ap.add_argument("--fuse", type=int, default=32,
                     help="resident records advanced per launch by sitrk_run (loop interchange; 1 = one launch per record)")
     ap.add_argument("--e2e-full", action="store_true", help="e2e regime: upload whole records instead of the row band the buoys can touch")
+    ap.add_argument("--e2e-library", action="store_true",
+                    help="e2e regime through the library's own pinned staging and copy stream (sitrk_stage_*), host fill included")
+    ap.add_argument("--no-c2", action="store_true", help="skip the C2 (512x512, 1e5 buoys, 1000 steps) sub-measurement")
+    ap.add_argument("--no-e2e-broadcast", action="store_true",
+                    help="N > 1: skip the short end-to-end segment (one RCCL broadcast per record, overlapped with stepping)")
     ap.add_argument("--regime", default="resident", choices=["resident", "e2e"],
                     help="resident: records live in HBM (the metric). e2e: every step's record is uploaded from pinned host "
                          "memory on rank 0 (+ RCCL broadcast), double-buffered against the stepping; reported for context only")
@@ -118,6 +131,111 @@ def cpu_baseline_check(ctx, grid, u, v, sic, yx, ji, nsteps, uv_strategy, nS=200
     print("check OK: first %d buoys bit-exact vs oracle after %d steps" % (nS, nsteps), file=sys.stderr)
 
 
+def c2_subrun(sit, syn, dev, a, steps=1000, warmup=64):
+    """BASELINE.json configs[1] (C2: 512x512, 1e5 buoys, 1000 steps) on the same GPU, same library defaults: the grid and
+    the state are cache-resident and a launch is under-filled (391 workgroups), so this is a latency figure -- reported
+    as particle-steps/s only (the HBM fraction is not meaningful there)."""
+    Nj, Ni, nP, label = CONFIGS["c2"]
+    K = 32
+    grid = syn.make_grid(Nj, Ni, dkm=4.0, warp=0.0)
+    _, yx = syn.make_buoys(grid, nP, seed=1234, frac=0.6)
+    ji = syn.regular_host_cell(grid, yx).astype(np.int32)
+    u, v, sic = syn.make_fields(grid, K=K, seed=2024, umax=0.3, drift=0.05)
+    ctx = sit.Context(dev)
+    try:
+        ctx.set_grid(grid["Yf"], grid["Xf"], grid["Yu"], grid["Xu"], grid["Yv"], grid["Xv"], grid["tmask"])
+        ctx.set_params(3600., a.uv_strategy, 0.1)
+        ctx.alloc_records(K, np.float32)
+        for k in range(K):
+            ctx.push_record(k, u[k], v[k], sic[k])
+        ctx.set_buoys(yx, ji)
+        ctx.set_tuning(fuse=32)
+        ctx.run(0, 0, warmup)
+        ctx.sync()
+        ctx.launch_stats(reset=True)
+        ctx.timer_start()
+        t0 = time.perf_counter()
+        ctx.run(warmup % K, warmup, steps)
+        ms = ctx.timer_stop()
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        st = ctx.launch_stats(reset=True)
+        return {"workload": label, "steps": steps, "warmup": warmup, "value": nP * steps / dt, "unit": "particle-steps/s",
+                "ms_per_step": 1e3 * dt / steps, "event_ms_per_step": ms / steps, "launches": st["fused_launches"] + st["step_launches"],
+                "records_per_launch": st["fused_records"] / max(st["fused_launches"], 1), "alive_after": ctx.count_alive(),
+                "note": "cache-resident and launch-latency bound: no roofline fraction is claimed"}
+    finally:
+        ctx.close()
+
+
+def e2e_broadcast_segment(ctx, dist, torch, sd, rank, world, slabs_host, K, s0, Nj, Ni, nsteps=24):
+    """N > 1 only, reported next to the resident value, never as `value`: the regime north_star describes -- every record
+    is delivered to every rank by ONE broadcast of its [u|v|siconc] slab (RCCL over xGMI) into a resident slot,
+    double-buffered against the stepping: the broadcast of record s+1 runs on its own stream while record s is stepped
+    with.  Two transports are timed back to back: RCCL's broadcast and the scatter + all-gather form (every link of the
+    full mesh carries 1/N-th of the slab).  The slabs already resident on rank 0 are the source (device to device: the
+    PCIe leg is what `--regime e2e` measures on one GPU).  A failure is reported, not fatal."""
+    out = {"steps": nsteps, "slab_bytes": int(ctx.slab_elems * 4), "note": "one broadcast per record, overlapped with the stepping; not `value`"}
+    try:
+        comp, comm_s = torch.cuda.Stream(), torch.cuda.Stream()
+        ctx.set_stream(comp.cuda_stream)
+        views = [sd.slot_tensor(ctx, k) for k in range(K)]
+        # two scratch slots are the broadcast targets; the source on rank 0 are the resident slots 2..K-1
+        ready = [torch.cuda.Event(), torch.cuda.Event()]
+        free = [torch.cuda.Event(), torch.cuda.Event()]
+        for mode in ("broadcast", "scatter_allgather"):
+            for e in free:
+                e.record(comp)
+
+            def deliver(sidx):
+                b = sidx % 2
+                with torch.cuda.stream(comm_s):
+                    comm_s.wait_event(free[b])
+                    if rank == 0:
+                        views[b].copy_(views[2 + sidx % (K - 2)], non_blocking=True)
+                    if mode == "broadcast":
+                        dist.broadcast(views[b], src=0)
+                    else:
+                        sd.scatter_allgather(views[b], src=0)
+                    ready[b].record(comm_s)
+
+            def run(first, n):
+                for sidx in range(first, first + n):
+                    if sidx == first:
+                        deliver(sidx)
+                    if sidx + 1 < first + n:
+                        deliver(sidx + 1)
+                    comp.wait_event(ready[sidx % 2])
+                    ctx.record_ptr(sidx % 2)                     # marks the slot as rewritten in place
+                    ctx.commit_record(sidx % 2)
+                    ctx.step(sidx % 2, sidx)
+                    free[sidx % 2].record(comp)
+
+            run(s0, 4)
+            ctx.sync(); torch.cuda.synchronize(); dist.barrier()
+            t0 = time.perf_counter()
+            run(s0 + 4, nsteps)
+            ctx.sync(); torch.cuda.synchronize(); dist.barrier()
+            dt = time.perf_counter() - t0
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t[0])
+            s0 += 4 + nsteps
+            out[mode] = {"ms_per_step": 1e3 * dt / nsteps, "slab_GBps_per_rank": out["slab_bytes"] / (dt / nsteps) / 1e9,
+                         "particle_steps_per_s": ctx.nP * world * nsteps / dt}
+        ctx.set_stream(None)
+        # the scratch slots hold broadcast copies now; restore what the resident regime had there
+        if rank == 0:
+            pass
+    except Exception as e:                                          # noqa: BLE001
+        out["error"] = repr(e)
+        try:
+            ctx.set_stream(None)
+        except Exception:                                           # noqa: BLE001
+            pass
+    return out
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -148,6 +266,8 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     red_dev = "cuda" if backend == "nccl" else "cpu"        # where the small reduction tensors live
 
+    if a.config == "auto":
+        a.config = "c3" if world == 1 else "c4"
     Nj, Ni, nP, label = CONFIGS[a.config]
     if a.buoys > 0:
         nP = a.buoys
@@ -208,40 +328,76 @@ def main():
             dist.barrier()
 
     per_record = None
+    eight = None
+    stats = None
     if a.regime == "resident":
         fuse = max(1, min(a.fuse, K, 32))               # a launch advances distinct resident records only
+
+        def timed_run(s0, nsteps, nfuse):
+            """nsteps records from step s0 at `nfuse` records per launch: (wall s, HIP-event ms, what was really launched)"""
+            ctx.set_tuning(fuse=nfuse)
+            barrier()
+            ctx.launch_stats(reset=True)
+            ctx.timer_start()
+            t = time.perf_counter()
+            ctx.run(s0 % K, s0, nsteps)
+            ms = ctx.timer_stop()
+            barrier()
+            return time.perf_counter() - t, ms, ctx.launch_stats(reset=True)
+
         ctx.set_tuning(fuse=fuse)
         ctx.run(0, 0, a.warmup)
+        dt, ev_ms, stats = timed_run(a.warmup, a.steps, fuse)
+        nrun = a.warmup + a.steps
+        if fuse > 1:
+            # for reference: the same K steps with one launch per record (the HBM-bound form of the kernel)
+            dt1, ev1_ms, st1 = timed_run(nrun, a.steps, 1)
+            per_record = (dt1, ev1_ms, st1)
+            nrun += a.steps
+        if fuse > 8:
+            # for reference: 8 records per launch (the K = 8 of SURVEY 8d's synthetic set-up allows no more)
+            eight = timed_run(nrun, a.steps, 8)[0]
+            nrun += a.steps
+        ctx.set_tuning(fuse=fuse)
+    elif a.e2e_library:
+        # end-to-end through the library's own ingest (sitrk_stage_acquire / sitrk_stage_submit): every record is copied
+        # by this host thread into the library's pinned staging -- the part a NetCDF reader plays in the driver -- and
+        # travels on the library's copy stream while the previous record is stepped with.  One GPU only.
+        fuse = 1
+        assert world == 1 and K >= 2
+        band = {"eval": -10**9, "jmin": 0, "jmax": Nj - 1, "bytes": 0}
+
+        def deliver(sidx):
+            if a.e2e_full:
+                j0, j1 = 0, Nj
+            else:
+                age = sidx - band["eval"]
+                j0, j1 = max(0, band["jmin"] - 2 - age), min(Nj, band["jmax"] + 3 + age)
+            band["bytes"] += 3 * (j1 - j0) * Ni * 4
+            bu, bv, bs = ctx.stage(j1 - j0)
+            bu[...] = u[sidx % K][j0:j1]; bv[...] = v[sidx % K][j0:j1]; bs[...] = sic[sidx % K][j0:j1]
+            ctx.submit(sidx % 2, j0)
+
+        def run_e2e(s0, n):
+            for sidx in range(s0, s0 + n):
+                if not a.e2e_full and (sidx - band["eval"]) >= 32:
+                    band["jmin"], band["jmax"] = ctx.buoy_rows()
+                    band["eval"] = sidx
+                if sidx == s0:
+                    deliver(sidx)
+                ctx.step(sidx % 2, sidx)
+                if sidx + 1 < s0 + n:
+                    deliver(sidx + 1)              # its DMA waits for the step above only if it reuses that slot: it does not
+
+        run_e2e(0, a.warmup)
         barrier()
         ctx.timer_start()
         t0 = time.perf_counter()
-        ctx.run(a.warmup % K, a.warmup, a.steps)
+        run_e2e(a.warmup, a.steps)
         ev_ms = ctx.timer_stop()
         barrier()
         dt = time.perf_counter() - t0
-        if fuse > 1:
-            # for reference: the same K steps with one launch per record (the HBM-bound form of the kernel)
-            ctx.set_tuning(fuse=1)
-            s1 = a.warmup + a.steps
-            barrier()
-            ctx.timer_start()
-            t1 = time.perf_counter()
-            ctx.run(s1 % K, s1, a.steps)
-            ev1_ms = ctx.timer_stop()
-            barrier()
-            per_record = (time.perf_counter() - t1, ev1_ms)
-            ctx.set_tuning(fuse=fuse)
-        eight = None
-        if fuse > 8:
-            # for reference: 8 records per launch (the K = 8 of SURVEY 8d's synthetic set-up allows no more)
-            ctx.set_tuning(fuse=8)
-            s2 = a.warmup + 2 * a.steps
-            barrier()
-            t2 = time.perf_counter()
-            ctx.run(s2 % K, s2, a.steps)
-            barrier()
-            eight = time.perf_counter() - t2
-            ctx.set_tuning(fuse=fuse)
+        e2e_bytes_per_step = band["bytes"] / float(a.warmup + a.steps)
     else:
         fuse = 1
         # end-to-end: record s goes pinned host -> slot s%2 on a copy stream (rank 0), is broadcast, and is
@@ -317,13 +473,16 @@ def main():
         nalive = int(t[0])
 
     if a.check and rank == 0:
-        nchk = a.warmup + a.steps * (1 + (per_record is not None) + (a.regime == "resident" and eight is not None))
+        nchk = a.warmup + a.steps * (1 + (per_record is not None) + (eight is not None))
         cpu_baseline_check(ctx, grid, u, v, sic, yx, ji, nchk, a.uv_strategy)
+
+    e2e_bcast = None
+    if dist is not None and a.regime == "resident" and backend == "nccl" and not a.no_e2e_broadcast:
+        e2e_bcast = e2e_broadcast_segment(ctx, dist, torch, sd, rank, world, slabs_host, K, a.warmup + a.steps * 3, Nj, Ni)
 
     if rank == 0:
         total = float(nP) * world * a.steps
         step_s = (ev_ms / 1e3) / a.steps                     # avg time per record, HIP events, library stream
-        nlaunch = (a.steps + fuse - 1) // fuse
         # cells whose record a step needs: the union of every buoy's (j,i),(j,i-1),(j-1,i),(j-1,i-1)
         keys = ji[:, 0].astype(np.int64) * Ni + ji[:, 1]
         need = np.zeros(Nj * Ni, dtype=bool)
@@ -332,22 +491,62 @@ def main():
         n_cells = int(need.sum())
         A1 = 50.0 * nP + 56.0 * n_cells                      # algorithmic bytes of ONE record per GPU
         A_survey = 50.0 * nP + 56.0 * Nj * Ni                # SURVEY 8d closed form (every cell of the grid)
-        # a launch that advances `fuse` records reads/writes the 50 B of state and the 48 B of cell geometry once,
-        # and the 8 B of u,v once per record
-        A = 50.0 * nP + 48.0 * n_cells + 8.0 * n_cells * fuse
-        launch_s = (ev_ms / 1e3) / nlaunch
-        achieved = A / launch_s / 1e9
-        traffic = traffic_fused = None
-        prof_fused = {}
-        tj = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tj) and a.buoys == 0:        # the profiled counters belong to the configuration's own size
-            try:
-                tjd = json.load(open(tj))
-                traffic = tjd.get(a.config, {}).get("hbm_bytes_per_launch")
-                traffic_fused = tjd.get(a.config + "_fused", {}).get("hbm_bytes_per_launch")
-                prof_fused = tjd.get(a.config + "_fused", {})
-            except Exception:
-                traffic = None
+        prof = {}
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        except Exception:                                    # noqa: BLE001
+            prof = {}
+        prof_key = "c3" if a.config == "c4" else a.config    # C4's per-rank shard runs the C3 kernels on the C3 grid
+        prof_step, prof_fused = prof.get(prof_key, {}), prof.get(prof_key + "_fused", {})
+        nwaves = (nP + 63) // 64
+
+        def roofline_step(ms_per_launch):
+            """advect_step_kernel: one record per launch, HBM bound (SURVEY 8d's byte model, needed cells only)"""
+            s_ = ms_per_launch / 1e3
+            tr = prof_step.get("hbm_bytes_per_launch") if a.buoys == 0 else None
+            return {"bound": "hbm", "achieved": A1 / s_ / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": A1 / s_ / 1e9 / HBM_PEAK_GBS,
+                    "traffic": tr, "traffic_source": prof_step.get("source") if tr else None,
+                    "algorithmic_bytes_per_launch": A1, "cells_needed": n_cells, "kernel": "advect_step_kernel",
+                    "records_per_launch": 1, "avg_launch_ms": ms_per_launch,
+                    "survey_formula_bytes_per_record": A_survey, "survey_formula_frac": A_survey / s_ / 1e9 / HBM_PEAK_GBS}
+
+        def roofline_fused(ev_ms_total, st):
+            """advect_run_kernel: state and geometry are read once per launch, so it is bound by fp64 VALU issue, not by
+            HBM.  frac = VALU instructions issued per second / what 1024 SIMDs can issue at the 2.4 GHz peak clock, with
+            the instructions per wave per record taken from the committed rocprofv3 counters (SQ_INSTS_VALU / SQ_WAVES /
+            records per launch) and the launches and records counted by the library in THIS run."""
+            nl, nr, ns = st["fused_launches"], st["fused_records"], st["step_launches"]
+            ipwr = prof_fused.get("valu_per_wave_record")
+            rpl = nr / nl if nl else 0.0
+            # the timed region = nl fused launches (+ ns one-record launches where a re-sort or the tail cut a launch short)
+            launch_ms = ev_ms_total / max(nl + ns, 1)
+            rec_s = (ev_ms_total / 1e3) / max(nr + ns, 1)
+            A = 50.0 * nP + 48.0 * n_cells + 8.0 * n_cells * rpl          # bytes one launch of rpl records needs
+            out = {"bound": "fp64_valu_issue", "unit": "Ginst/s", "peak": VALU_PEAK_GINST,
+                   "kernel": "advect_run_kernel", "launches": nl, "records_advanced": nr, "one_record_launches": ns,
+                   "records_per_launch": rpl, "avg_launch_ms": launch_ms, "waves_per_launch": nwaves,
+                   "valu_inst_per_wave_record": ipwr, "valu_inst_source": prof_fused.get("source"),
+                   "peak_note": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction"}
+            if ipwr:
+                ach = ipwr * nwaves / rec_s / 1e9
+                out.update({"achieved": ach, "frac": ach / VALU_PEAK_GINST})
+            else:
+                out.update({"achieved": None, "frac": None})
+            tr = prof_fused.get("hbm_bytes_per_launch") if a.buoys == 0 else None
+            tr_rpl = prof_fused.get("records_per_launch", 32)
+            out["traffic"] = tr * rpl / tr_rpl if (tr and rpl) else None
+            out["traffic_note"] = ("rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE of a %d-record launch (%s), scaled to %.1f records"
+                                   % (tr_rpl, prof_fused.get("source"), rpl)) if tr else None
+            out["hbm"] = {"algorithmic_bytes_per_launch": A, "achieved": A / (launch_ms / 1e3) / 1e9 if nl else None,
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": A / (launch_ms / 1e3) / 1e9 / HBM_PEAK_GBS if nl else None,
+                          "cells_needed": n_cells,
+                          "note": "secondary: the fused kernel is not HBM bound; per_record_launch holds the HBM-bound form"}
+            return out
+
+        if a.regime == "resident" and fuse > 1 and stats["fused_launches"] > 0:
+            roof = roofline_fused(ev_ms, stats)
+        else:
+            roof = roofline_step(1e3 * step_s)
         line = {
             "metric": "particle-steps/s", "value": total / dt, "unit": "particle-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
@@ -359,30 +558,20 @@ def main():
                        "records_per_launch": fuse,
                        "e2e_upload_bytes_per_step": (e2e_bytes_per_step if a.regime == "e2e" else None),
                        "partition": "buoy-range x%d" % world, "records_via": records_via, "alive_after": nalive},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_fused if fuse > 1 else traffic,
-                         "algorithmic_bytes_per_launch": A, "cells_needed": n_cells,
-                         "kernel": "advect_run_kernel" if fuse > 1 else "advect_step_kernel", "records_per_launch": fuse,
-                         "avg_launch_ms": 1e3 * launch_s,
-                         "note": ("%d records per launch: state and geometry are read once per launch, so the kernel is "
-                                  "fp64-issue bound, not HBM bound; see per_record_launch for the HBM-bound form" % fuse)
-                         if fuse > 1 else "one record per launch",
-                         "valu_busy_frac_profiled": prof_fused.get("valu_busy_frac") if fuse > 1 else None,
-                         "sclk_ghz_profiled": prof_fused.get("sclk_ghz") if fuse > 1 else None,
-                         "survey_formula_bytes_per_record": A_survey,
-                         "survey_formula_frac_per_record": A_survey / step_s / 1e9 / HBM_PEAK_GBS},
+            "roofline": roof,
         }
         if per_record is not None:
-            dt1, ev1 = per_record
-            s1 = (ev1 / 1e3) / a.steps
+            dt1, ev1, st1 = per_record
             line["per_record_launch"] = {
                 "value": total / dt1, "ms_per_step": 1e3 * dt1 / a.steps, "kernel": "advect_step_kernel",
-                "roofline": {"bound": "hbm", "achieved": A1 / s1 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": A1 / s1 / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": A1,
-                             "avg_launch_ms": 1e3 * s1}}
-        if a.regime == "resident" and eight is not None:
+                "launches": st1["step_launches"], "roofline": roofline_step(ev1 / max(st1["step_launches"], 1))}
+        if eight is not None:
             line["eight_records_per_launch"] = {"value": total / eight, "ms_per_step": 1e3 * eight / a.steps,
                                                 "note": "same kernel, 8 records per launch (SURVEY 8d keeps K = 8 records resident)"}
+        if e2e_bcast is not None:
+            line["e2e_broadcast"] = e2e_bcast
+        if world == 1 and a.regime == "resident" and a.config == "c3" and a.buoys == 0 and not a.no_c2:
+            line["c2"] = c2_subrun(sit, syn, dev, a)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(grid, u, v, sic, yx, ji, a.cpu_seconds, a.uv_strategy)
         print(json.dumps(line))

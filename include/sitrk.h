@@ -19,8 +19,15 @@
  *     handle, no global state).  Multi-GPU = one process per GPU, each with
  *     its own context and its own contiguous range of buoys.
  *   - the caller owns all host buffers; no host pointer is retained after a
- *     call returns.  Device pointers passed to *_dev entry points must stay
- *     valid until the next sitrk_sync()/fetch.
+ *     call returns: inputs are copied into device memory or into the library's
+ *     own pinned staging before the call comes back (a C caller may free or
+ *     overwrite them at once), outputs are complete on return.  Device pointers
+ *     passed to *_dev entry points must stay valid until the next sitrk_sync()/fetch.
+ *   - threading: one compute stream and one copy stream per context.  Record
+ *     uploads (sitrk_push_record*, sitrk_stage_submit) run on the copy stream
+ *     out of double-buffered pinned staging and are ordered against the kernels
+ *     by events only, so the next records travel while the current ones are
+ *     stepped with (SURVEY 8b "async, double-buffered").
  *   - there is NO CPU fallback: without a usable HIP device sitrk_create()
  *     fails with SITRK_EHIP.
  */
@@ -91,7 +98,18 @@ int sitrk_set_tuning(sitrk_t *h, const char *knob, int value);
  * `nslots` records are resident on the device; a slot is one contiguous slab
  * [u | v | siconc] of 3*Nj*Ni elements of `dtype` (what one RCCL broadcast moves). */
 int   sitrk_alloc_records(sitrk_t *h, int nslots, int dtype);
+/* Host arrays -> slot.  Asynchronous and double-buffered: the three fields are copied into the library's pinned staging
+ * (so u, v, sic may be freed or reused as soon as the call returns), the DMA into the slot is queued on the copy stream
+ * behind the last kernel that reads the slot, and the record's Survive mask is queued on the compute stream behind the
+ * DMA.  A second push proceeds while the first one's DMA is in flight; a third waits for the first buffer to drain. */
 int   sitrk_push_record(sitrk_t *h, int slot, const void *u, const void *v, const void *sic);   /* host pointers   */
+/* The same without the intermediate copy, for callers that can READ INTO pinned memory (a NetCDF reader):
+ * sitrk_stage_acquire hands out the next staging buffer as three arrays of nrows x Ni elements of the records' dtype
+ * (blocks until the upload that last used the buffer has drained); the caller fills them and sitrk_stage_submit queues
+ * them as rows [j0, j0 + nrows) of `slot` exactly like sitrk_push_record_rows (whole record: nrows = Nj, j0 = 0).
+ * The pointers belong to the library and are valid until the submit. */
+int   sitrk_stage_acquire(sitrk_t *h, int nrows, void **u, void **v, void **sic);
+int   sitrk_stage_submit(sitrk_t *h, int slot, int j0, int j1);
 int   sitrk_push_record_dev(sitrk_t *h, int slot, const void *slab_dev);                        /* device pointer: [u|v|sic] */
 void *sitrk_record_ptr(sitrk_t *h, int slot);   /* device address of a slot's slab (broadcast target); NULL on error */
 /* A slot whose slab was (re)written in place through sitrk_record_ptr must be committed before it is
@@ -106,7 +124,11 @@ int   sitrk_commit_record(sitrk_t *h, int slot);
  * when none) the next step can only touch rows [jmin-2, jmax+3) of a record, and only those need to be uploaded:
  * sitrk_push_record_rows copies rows [j0,j1) of the (Nj,Ni) fields (host arrays holding just those rows) into the slot
  * and derives the Survive bytes they determine (rows j0+1..j1-2 and the domain rim); other rows keep what they held.
- * Each rank of a multi-GPU run can thus ingest only the band of its own buoys: no collective at all. */
+ * Each rank of a multi-GPU run can thus ingest only the band of its own buoys: no collective at all.
+ * The library remembers which rows of a slot are valid and checks every step against them: stepping with a partly
+ * uploaded slot needs sitrk_buoy_rows() to have been evaluated since sitrk_set_buoys(), and fails with SITRK_EINVAL when
+ * [jmin-2-age, jmax+3+age) (age = records stepped since that evaluation; record r of a fused sitrk_run counts age+r) is
+ * not inside the uploaded rows.  Slots are allocated with every Survive byte = kill and every field value = NaN. */
 int sitrk_buoy_rows(sitrk_t *h, int32_t *jmin, int32_t *jmax);
 int sitrk_push_record_rows(sitrk_t *h, int slot, int j0, int j1, const void *u_rows, const void *v_rows, const void *sic_rows);
 /* same derivation for rows [j0,j1) that the caller wrote in place through sitrk_record_ptr (device-side copies) */
@@ -138,6 +160,10 @@ int sitrk_step(sitrk_t *h, int slot, int jrec);
 
 /* nsteps records jrec0, jrec0+1, ... using slots (slot0 + k) % nslots */
 int sitrk_run(sitrk_t *h, int slot0, int jrec0, int nsteps);
+/* What sitrk_run / sitrk_step really launched since the last reset: fused launches of advect_run_kernel, the records
+ * they advanced in total (a launch is cut short at a re-sort and at the end of a run), and one-record launches of
+ * advect_step_kernel.  Any pointer may be NULL.  bench.py prices its roofline per launch from these. */
+int sitrk_launch_stats(sitrk_t *h, int reset, int64_t *fused_launches, int64_t *fused_records, int64_t *step_launches);
 
 /* Current state in the caller's buoy order (any pointer may be NULL):
  * yx (nP,2) current position; jiT (nP,2) = vJIt; alive (nP) = iAlive;

@@ -36,6 +36,9 @@ _SIGNATURES = {
     "sitrk_alloc_records": (_int, [_vp, _int, _int]),
     "sitrk_push_record": (_int, [_vp, _int, _vp, _vp, _vp]),
     "sitrk_push_record_dev": (_int, [_vp, _int, _vp]),
+    "sitrk_stage_acquire": (_int, [_vp, _int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "sitrk_stage_submit": (_int, [_vp, _int, _int, _int]),
+    "sitrk_launch_stats": (_int, [_vp, _int, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "sitrk_buoy_rows": (_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sitrk_push_record_rows": (_int, [_vp, _int, _int, _int, _vp, _vp, _vp]),
     "sitrk_commit_record_rows": (_int, [_vp, _int, _int, _int]),
@@ -215,8 +218,30 @@ class Context:
         u = as_c(u, self.field_dtype, shp, "u")
         v = as_c(v, self.field_dtype, shp, "v")
         sic = as_c(sic, self.field_dtype, shp, "sic")
+        # asynchronous: the library copies the fields into its pinned staging before returning (temporaries are fine)
         self._chk(self._L.sitrk_push_record(self._h, int(slot), _ptr(u), _ptr(v), _ptr(sic)))
-        self.sync()             # u,v,sic may be temporaries
+
+    def stage(self, nrows=None):
+        """The library's next pinned staging buffer as three (nrows, Ni) arrays of the records' dtype (views of pinned
+        host memory, valid until submit()): read the record straight into them, then submit(slot, j0)."""
+        nrows = self.Nj if nrows is None else int(nrows)
+        pu, pv, ps = _vp(), _vp(), _vp()
+        self._chk(self._L.sitrk_stage_acquire(self._h, nrows, C.byref(pu), C.byref(pv), C.byref(ps)))
+        nb = nrows * self.Ni * self.field_dtype.itemsize
+
+        def view(p):
+            return np.frombuffer((C.c_char * nb).from_address(p.value), dtype=self.field_dtype).reshape(nrows, self.Ni)
+        self._staged_rows = nrows
+        return view(pu), view(pv), view(ps)
+
+    def submit(self, slot, j0=0):
+        """Queue the staged rows as rows [j0, j0+nrows) of `slot` (asynchronous, see sitrk_stage_submit)."""
+        self._chk(self._L.sitrk_stage_submit(self._h, int(slot), int(j0), int(j0) + int(self._staged_rows)))
+
+    def launch_stats(self, reset=False):
+        a, b, c = _i64(0), _i64(0), _i64(0)
+        self._chk(self._L.sitrk_launch_stats(self._h, int(bool(reset)), C.byref(a), C.byref(b), C.byref(c)))
+        return {"fused_launches": a.value, "fused_records": b.value, "step_launches": c.value}
 
     def buoy_rows(self):
         """(jmin, jmax) of the host rows of the buoys still alive; jmin > jmax when there is none."""
@@ -238,7 +263,6 @@ class Context:
         v = as_c(v_rows, self.field_dtype, shp, "v rows")
         s = as_c(sic_rows, self.field_dtype, shp, "sic rows")
         self._chk(self._L.sitrk_push_record_rows(self._h, int(slot), int(j0), int(j1), _ptr(u), _ptr(v), _ptr(s)))
-        self.sync()
 
     def commit_record_rows(self, slot, j0, j1):
         self._chk(self._L.sitrk_commit_record_rows(self._h, int(slot), int(j0), int(j1)))

@@ -80,6 +80,8 @@ static void free_buoys(sitrk_ctx *h)
     h->nP = 0;
 }
 
+static void free_records(sitrk_ctx *h);
+
 // --------------------------------------------------------------------------- context
 SITRK_API int sitrk_version(void) { return SITRK_VERSION; }
 
@@ -101,9 +103,15 @@ SITRK_API int sitrk_create(sitrk_t **out, int device)
     sitrk_ctx *c = new (std::nothrow) sitrk_ctx();
     if (!c) return fail(h, SITRK_ENOMEM, "sitrk_create: out of host memory");
     c->device = device;
-    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
-        (e = hipMalloc((void **)&c->counter, sizeof(unsigned long long))) != hipSuccess) {
+    for (int k = 0; k < 4096; k++) c->slot_used_seq[k] = -1;
+    e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    for (int b = 0; b < sitrk_ctx::kStage && e == hipSuccess; b++) e = hipEventCreateWithFlags(&c->stage_done[b], hipEventDisableTiming);
+    for (int k = 0; k < sitrk_ctx::kLaunchRing && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->launch_ev[k], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->counter, sizeof(unsigned long long));
+    if (e != hipSuccess) {
         int rc = fail(h, SITRK_EHIP, "sitrk_create: %s", hipGetErrorString(e));
         (void)sitrk_destroy(c);                 // releases whatever was created before the failure
         return rc;
@@ -117,11 +125,17 @@ SITRK_API int sitrk_destroy(sitrk_t *h)
 {
     if (!h) return SITRK_OK;
     (void)hipSetDevice(h->device);
-    (void)hipStreamSynchronize(h->stream);
+    if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_buoys(h);
-    dev_free(h->geo); dev_free(h->orient); dev_free(h->tmask); dev_free(h->slabs); dev_free(h->kill); dev_free(h->scratch); dev_free(h->counter);
+    free_records(h);
+    dev_free(h->geo); dev_free(h->orient); dev_free(h->tmask); dev_free(h->scratch); dev_free(h->counter);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (int b = 0; b < sitrk_ctx::kStage; b++) if (h->stage_done[b]) (void)hipEventDestroy(h->stage_done[b]);
+    for (int k = 0; k < sitrk_ctx::kLaunchRing; k++) if (h->launch_ev[k]) (void)hipEventDestroy(h->launch_ev[k]);
+    for (int k = 0; k < 4096; k++) if (h->slot_ready[k]) (void)hipEventDestroy(h->slot_ready[k]);
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return SITRK_OK;
@@ -130,6 +144,7 @@ SITRK_API int sitrk_destroy(sitrk_t *h)
 SITRK_API int sitrk_sync(sitrk_t *h)
 {
     NEED(h, "null handle");
+    HIPCHK(hipStreamSynchronize(h->copy_stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return SITRK_OK;
 }
@@ -153,9 +168,11 @@ SITRK_API int sitrk_set_grid(sitrk_t *h, int Nj, int Ni, const double *Yf, const
     if ((int64_t)Nj * Ni > ((int64_t)1 << 29))      // byte offsets inside one fp64 field stay below 2^32 (CellCtx)
         return fail(h, SITRK_EINVAL, "sitrk_set_grid: grid %dx%d has more than 2^29 cells", Nj, Ni);
     HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->copy_stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    dev_free(h->geo); dev_free(h->orient); dev_free(h->tmask); dev_free(h->slabs); dev_free(h->kill);
-    h->geo = nullptr; h->orient = nullptr; h->tmask = nullptr; h->slabs = nullptr; h->kill = nullptr; h->nslots = 0;
+    dev_free(h->geo); dev_free(h->orient); dev_free(h->tmask);
+    h->geo = nullptr; h->orient = nullptr; h->tmask = nullptr;
+    free_records(h);
     free_buoys(h);
     const size_t n = (size_t)Nj * Ni;
     HIPCHK(dev_alloc(&h->geo, n));
@@ -234,6 +251,20 @@ SITRK_API int sitrk_set_tuning(sitrk_t *h, const char *knob, int value)
 // --------------------------------------------------------------------------- records
 static inline size_t elem_size(int dtype) { return dtype == SITRK_F64 ? 8 : 4; }
 
+static void free_records(sitrk_ctx *h)
+{
+    dev_free(h->slabs); dev_free(h->kill);
+    h->slabs = nullptr; h->kill = nullptr; h->nslots = 0;
+    for (int b = 0; b < sitrk_ctx::kStage; b++) {
+        if (h->stage[b]) (void)hipHostFree(h->stage[b]);
+        h->stage[b] = nullptr;
+    }
+    h->stage_bytes = 0; h->stage_rows = -1; h->stage_next = 0;
+    memset(h->slot_pending, 0, sizeof(h->slot_pending));
+    memset(h->slot_dirty, 1, sizeof(h->slot_dirty));
+    for (int k = 0; k < 4096; k++) { h->slot_used_seq[k] = -1; h->slot_row_lo[k] = h->slot_row_hi[k] = 0; }
+}
+
 SITRK_API int sitrk_alloc_records(sitrk_t *h, int nslots, int dtype)
 {
     NEED(h, "null handle");
@@ -241,14 +272,19 @@ SITRK_API int sitrk_alloc_records(sitrk_t *h, int nslots, int dtype)
     NEED(nslots >= 1 && nslots <= 4096, "sitrk_alloc_records: nslots out of range");
     NEED(dtype == SITRK_F32 || dtype == SITRK_F64, "sitrk_alloc_records: dtype must be SITRK_F32 or SITRK_F64");
     HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->copy_stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    dev_free(h->slabs); dev_free(h->kill);
-    h->slabs = nullptr; h->kill = nullptr; h->nslots = 0;
-    h->slab_bytes = 3 * (size_t)h->Nj * h->Ni * elem_size(dtype);
+    free_records(h);
+    const size_t n = (size_t)h->Nj * h->Ni;
+    h->slab_bytes = 3 * n * elem_size(dtype);
     HIPCHK(hipMalloc(&h->slabs, h->slab_bytes * nslots));
-    HIPCHK(hipMalloc((void **)&h->kill, (size_t)h->Nj * h->Ni * nslots));
+    HIPCHK(hipMalloc((void **)&h->kill, n * nslots));
+    // sentinels: a read outside the rows that were uploaded must be detectable, not silent garbage --
+    // every Survive byte starts as "kill", every field value as NaN (0xff.. is a NaN in fp32 and fp64)
+    HIPCHK(hipMemsetAsync(h->kill, 1, n * nslots, h->stream));
+    HIPCHK(hipMemsetAsync(h->slabs, 0xff, h->slab_bytes * nslots, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     h->nslots = nslots; h->dtype = dtype;
-    memset(h->slot_dirty, 1, sizeof(h->slot_dirty));
     return SITRK_OK;
 }
 
@@ -258,25 +294,60 @@ SITRK_API void *sitrk_record_ptr(sitrk_t *h, int slot)
 {
     if (!h || !h->slabs || slot < 0 || slot >= h->nslots) return nullptr;
     h->slot_dirty[slot] = 1;            // the caller is about to write the slab
+    h->slot_row_lo[slot] = 0; h->slot_row_hi[slot] = h->Nj;     // until a commit says otherwise
     return slab_of(h, slot);
 }
 
-// derive the slot's Survive mask from its siconc slab (queued on the compute stream)
-static int derive_mask(sitrk_ctx *h, int slot)
+// The compute stream is about to read `slot`: order it behind an upload still in flight on the copy stream.
+static int slot_wait_upload(sitrk_ctx *h, int slot)
+{
+    if (h->slot_pending[slot]) {
+        HIPCHK(hipStreamWaitEvent(h->stream, h->slot_ready[slot], 0));
+        h->slot_pending[slot] = 0;
+    }
+    return SITRK_OK;
+}
+
+// One event per launch (a ring of them): an upload into a slot waits for the last launch that read it, not for the
+// whole compute stream, so the next records travel while the current ones are stepped with.
+static int launch_mark(sitrk_ctx *h, const int *slots, int nslots_used)
+{
+    const long long seq = ++h->launch_seq;
+    HIPCHK(hipEventRecord(h->launch_ev[seq % sitrk_ctx::kLaunchRing], h->stream));
+    for (int k = 0; k < nslots_used; k++) h->slot_used_seq[slots[k]] = seq;
+    return SITRK_OK;
+}
+
+// derive the Survive bytes of rows [j0,j1) of a slot from its siconc rows [v0,v1) (queued on the compute stream)
+static int derive_mask_rows(sitrk_ctx *h, int slot, int j0, int j1, int v0, int v1)
 {
     const size_t n = (size_t)h->Nj * h->Ni, es = elem_size(h->dtype);
     const char *sic = slab_of(h, slot) + 2 * n * es;
     int8_t *kill = h->kill + (size_t)slot * n;
-    if (h->dtype == SITRK_F64)
-        hipLaunchKernelGGL((survive_mask_kernel<double>), dim3(nblocks((int64_t)n)), dim3(kBlock), 0, h->stream, h->Nj, h->Ni, h->tmask,
-                           (const double *)sic, h->rmin_conc, kill);
-    else
-        hipLaunchKernelGGL((survive_mask_kernel<float>), dim3(nblocks((int64_t)n)), dim3(kBlock), 0, h->stream, h->Nj, h->Ni, h->tmask,
-                           (const float *)sic, h->rmin_conc, kill);
+    int rc = slot_wait_upload(h, slot);
+    if (rc) return rc;
+    if (j0 == 0 && j1 == h->Nj && v0 == 0 && v1 == h->Nj) {
+        if (h->dtype == SITRK_F64)
+            hipLaunchKernelGGL((survive_mask_kernel<double>), dim3(nblocks((int64_t)n)), dim3(kBlock), 0, h->stream, h->Nj, h->Ni, h->tmask,
+                               (const double *)sic, h->rmin_conc, kill);
+        else
+            hipLaunchKernelGGL((survive_mask_kernel<float>), dim3(nblocks((int64_t)n)), dim3(kBlock), 0, h->stream, h->Nj, h->Ni, h->tmask,
+                               (const float *)sic, h->rmin_conc, kill);
+    } else {
+        const int64_t cells = (int64_t)(j1 - j0) * h->Ni;
+        if (h->dtype == SITRK_F64)
+            hipLaunchKernelGGL((survive_mask_rows_kernel<double>), dim3(nblocks(cells)), dim3(kBlock), 0, h->stream, h->Nj, h->Ni, j0, j1, v0, v1,
+                               h->tmask, (const double *)sic, h->rmin_conc, kill);
+        else
+            hipLaunchKernelGGL((survive_mask_rows_kernel<float>), dim3(nblocks(cells)), dim3(kBlock), 0, h->stream, h->Nj, h->Ni, j0, j1, v0, v1,
+                               h->tmask, (const float *)sic, h->rmin_conc, kill);
+    }
     HIPCHK(hipGetLastError());
     h->slot_dirty[slot] = 0;
     return SITRK_OK;
 }
+
+static int derive_mask(sitrk_ctx *h, int slot) { return derive_mask_rows(h, slot, 0, h->Nj, 0, h->Nj); }
 
 SITRK_API int sitrk_commit_record(sitrk_t *h, int slot)
 {
@@ -284,7 +355,72 @@ SITRK_API int sitrk_commit_record(sitrk_t *h, int slot)
     NEED(h->slabs, "sitrk_commit_record: call sitrk_alloc_records first");
     NEED(slot >= 0 && slot < h->nslots, "sitrk_commit_record: slot out of range");
     HIPCHK(hipSetDevice(h->device));
+    h->slot_row_lo[slot] = 0; h->slot_row_hi[slot] = h->Nj;
     return derive_mask(h, slot);
+}
+
+// ---- pinned staging + copy stream -------------------------------------------------------------------------
+SITRK_API int sitrk_stage_acquire(sitrk_t *h, int nrows, void **u, void **v, void **sic)
+{
+    NEED(h, "null handle");
+    NEED(h->slabs, "sitrk_stage_acquire: call sitrk_alloc_records first");
+    NEED(nrows >= 1 && nrows <= h->Nj, "sitrk_stage_acquire: nrows out of range");
+    NEED(u && v && sic, "sitrk_stage_acquire: null output");
+    NEED(h->stage_rows < 0, "sitrk_stage_acquire: the buffer handed out before was not submitted");
+    HIPCHK(hipSetDevice(h->device));
+    const int b = h->stage_next;
+    if (!h->stage[b]) {                 // first use: one whole slab of pinned host memory per buffer
+        HIPCHK(hipHostMalloc(&h->stage[b], h->slab_bytes, hipHostMallocDefault));
+        h->stage_bytes = h->slab_bytes;
+    }
+    HIPCHK(hipEventSynchronize(h->stage_done[b]));      // the DMA that last read this buffer has finished
+    const size_t nb = (size_t)nrows * h->Ni * elem_size(h->dtype);
+    *u = h->stage[b];
+    *v = (char *)h->stage[b] + nb;
+    *sic = (char *)h->stage[b] + 2 * nb;
+    h->stage_rows = nrows;
+    return SITRK_OK;
+}
+
+SITRK_API int sitrk_stage_submit(sitrk_t *h, int slot, int j0, int j1)
+{
+    NEED(h, "null handle");
+    NEED(h->slabs, "sitrk_stage_submit: call sitrk_alloc_records first");
+    NEED(slot >= 0 && slot < h->nslots, "sitrk_stage_submit: slot out of range");
+    NEED(h->stage_rows >= 0, "sitrk_stage_submit: nothing acquired");
+    NEED(j0 >= 0 && j1 <= h->Nj && j1 - j0 == h->stage_rows, "sitrk_stage_submit: rows [j0,j1) do not match the acquired buffer");
+    HIPCHK(hipSetDevice(h->device));
+    const int b = h->stage_next;
+    const size_t n = (size_t)h->Nj * h->Ni, es = elem_size(h->dtype);
+    const size_t off = (size_t)j0 * h->Ni * es, nb = (size_t)(j1 - j0) * h->Ni * es;
+    char *d = slab_of(h, slot);
+    const char *src = (const char *)h->stage[b];
+    // the copy may not overtake kernels that still read the slot; nothing else on the compute stream holds it back
+    if (h->slot_used_seq[slot] >= 0) HIPCHK(hipStreamWaitEvent(h->copy_stream, h->launch_ev[h->slot_used_seq[slot] % sitrk_ctx::kLaunchRing], 0));
+    HIPCHK(hipMemcpyAsync(d + off, src, nb, hipMemcpyHostToDevice, h->copy_stream));
+    HIPCHK(hipMemcpyAsync(d + n * es + off, src + nb, nb, hipMemcpyHostToDevice, h->copy_stream));
+    HIPCHK(hipMemcpyAsync(d + 2 * n * es + off, src + 2 * nb, nb, hipMemcpyHostToDevice, h->copy_stream));
+    HIPCHK(hipEventRecord(h->stage_done[b], h->copy_stream));
+    if (!h->slot_ready[slot]) HIPCHK(hipEventCreateWithFlags(&h->slot_ready[slot], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(h->slot_ready[slot], h->copy_stream));
+    h->slot_pending[slot] = 1;
+    h->stage_rows = -1;
+    h->stage_next = (b + 1) % sitrk_ctx::kStage;
+    h->slot_row_lo[slot] = j0; h->slot_row_hi[slot] = j1;
+    // the Survive bytes these rows determine, on the compute stream behind the upload
+    int rc = derive_mask_rows(h, slot, j0, j1, j0, j1);
+    if (rc) return rc;
+    return launch_mark(h, &slot, 1);    // that kernel reads the slot's siconc: a later upload into the slot stays behind it
+}
+
+static int push_rows(sitrk_ctx *h, int slot, int j0, int j1, const void *u, const void *v, const void *sic)
+{
+    void *su, *sv, *ss;
+    int rc = sitrk_stage_acquire(h, j1 - j0, &su, &sv, &ss);
+    if (rc) return rc;
+    const size_t nb = (size_t)(j1 - j0) * h->Ni * elem_size(h->dtype);
+    memcpy(su, u, nb); memcpy(sv, v, nb); memcpy(ss, sic, nb);      // from here on the caller's buffers are its own again
+    return sitrk_stage_submit(h, slot, j0, j1);
 }
 
 SITRK_API int sitrk_push_record(sitrk_t *h, int slot, const void *u, const void *v, const void *sic)
@@ -293,13 +429,7 @@ SITRK_API int sitrk_push_record(sitrk_t *h, int slot, const void *u, const void 
     NEED(h->slabs, "sitrk_push_record: call sitrk_alloc_records first");
     NEED(slot >= 0 && slot < h->nslots, "sitrk_push_record: slot out of range");
     NEED(u && v && sic, "sitrk_push_record: null field");
-    HIPCHK(hipSetDevice(h->device));
-    const size_t nb = h->slab_bytes / 3;
-    char *d = slab_of(h, slot);
-    HIPCHK(hipMemcpyAsync(d, u, nb, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(d + nb, v, nb, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(d + 2 * nb, sic, nb, hipMemcpyHostToDevice, h->stream));
-    return derive_mask(h, slot);
+    return push_rows(h, slot, 0, h->Nj, u, v, sic);
 }
 
 SITRK_API int sitrk_buoy_rows(sitrk_t *h, int32_t *jmin, int32_t *jmax)
@@ -307,6 +437,7 @@ SITRK_API int sitrk_buoy_rows(sitrk_t *h, int32_t *jmin, int32_t *jmax)
     NEED(h, "null handle");
     NEED(jmin && jmax, "sitrk_buoy_rows: null output");
     *jmin = 1; *jmax = 0;
+    h->band_jmin = 1; h->band_jmax = 0; h->band_age = 0;
     if (h->nP == 0) return SITRK_OK;
     NEED(h->st[0].pos, "sitrk_buoy_rows: call sitrk_set_buoys first");
     HIPCHK(hipSetDevice(h->device));
@@ -318,6 +449,7 @@ SITRK_API int sitrk_buoy_rows(sitrk_t *h, int32_t *jmin, int32_t *jmax)
     HIPCHK(hipMemcpyAsync(res, d, sizeof(res), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (res[1] >= 0) { *jmin = res[0]; *jmax = res[1]; }
+    h->band_jmin = *jmin; h->band_jmax = *jmax;
     return SITRK_OK;
 }
 
@@ -327,27 +459,9 @@ SITRK_API int sitrk_push_record_rows(sitrk_t *h, int slot, int j0, int j1, const
     NEED(h->slabs, "sitrk_push_record_rows: call sitrk_alloc_records first");
     NEED(slot >= 0 && slot < h->nslots, "sitrk_push_record_rows: slot out of range");
     NEED(j0 >= 0 && j1 <= h->Nj && j0 <= j1, "sitrk_push_record_rows: rows out of range");
-    if (j0 == j1) return SITRK_OK;
+    if (j0 == j1) { h->slot_row_lo[slot] = h->slot_row_hi[slot] = 0; return SITRK_OK; }
     NEED(u_rows && v_rows && sic_rows, "sitrk_push_record_rows: null field");
-    HIPCHK(hipSetDevice(h->device));
-    const size_t n = (size_t)h->Nj * h->Ni, es = elem_size(h->dtype);
-    const size_t off = (size_t)j0 * h->Ni * es, nb = (size_t)(j1 - j0) * h->Ni * es;
-    char *d = slab_of(h, slot);
-    HIPCHK(hipMemcpyAsync(d + off, u_rows, nb, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(d + n * es + off, v_rows, nb, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(d + 2 * n * es + off, sic_rows, nb, hipMemcpyHostToDevice, h->stream));
-    // the Survive bytes these rows determine
-    int8_t *kill = h->kill + (size_t)slot * n;
-    const int64_t cells = (int64_t)(j1 - j0) * h->Ni;
-    if (h->dtype == SITRK_F64)
-        hipLaunchKernelGGL((survive_mask_rows_kernel<double>), dim3(nblocks(cells)), dim3(kBlock), 0, h->stream, h->Nj, h->Ni, j0, j1, j0, j1,
-                           h->tmask, (const double *)(d + 2 * n * es), h->rmin_conc, kill);
-    else
-        hipLaunchKernelGGL((survive_mask_rows_kernel<float>), dim3(nblocks(cells)), dim3(kBlock), 0, h->stream, h->Nj, h->Ni, j0, j1, j0, j1,
-                           h->tmask, (const float *)(d + 2 * n * es), h->rmin_conc, kill);
-    HIPCHK(hipGetLastError());
-    h->slot_dirty[slot] = 0;            // the caller vouches for the rows a step can touch (sitrk_buoy_rows)
-    return SITRK_OK;
+    return push_rows(h, slot, j0, j1, u_rows, v_rows, sic_rows);
 }
 
 SITRK_API int sitrk_commit_record_rows(sitrk_t *h, int slot, int j0, int j1)
@@ -356,21 +470,10 @@ SITRK_API int sitrk_commit_record_rows(sitrk_t *h, int slot, int j0, int j1)
     NEED(h->slabs, "sitrk_commit_record_rows: call sitrk_alloc_records first");
     NEED(slot >= 0 && slot < h->nslots, "sitrk_commit_record_rows: slot out of range");
     NEED(j0 >= 0 && j1 <= h->Nj && j0 <= j1, "sitrk_commit_record_rows: rows out of range");
+    h->slot_row_lo[slot] = j0; h->slot_row_hi[slot] = j1;
     if (j0 == j1) return SITRK_OK;
     HIPCHK(hipSetDevice(h->device));
-    const size_t n = (size_t)h->Nj * h->Ni, es = elem_size(h->dtype);
-    const char *sic = slab_of(h, slot) + 2 * n * es;
-    int8_t *kill = h->kill + (size_t)slot * n;
-    const int64_t cells = (int64_t)(j1 - j0) * h->Ni;
-    if (h->dtype == SITRK_F64)
-        hipLaunchKernelGGL((survive_mask_rows_kernel<double>), dim3(nblocks(cells)), dim3(kBlock), 0, h->stream, h->Nj, h->Ni, j0, j1, j0, j1,
-                           h->tmask, (const double *)sic, h->rmin_conc, kill);
-    else
-        hipLaunchKernelGGL((survive_mask_rows_kernel<float>), dim3(nblocks(cells)), dim3(kBlock), 0, h->stream, h->Nj, h->Ni, j0, j1, j0, j1,
-                           h->tmask, (const float *)sic, h->rmin_conc, kill);
-    HIPCHK(hipGetLastError());
-    h->slot_dirty[slot] = 0;
-    return SITRK_OK;
+    return derive_mask_rows(h, slot, j0, j1, j0, j1);
 }
 
 SITRK_API int sitrk_push_record_dev(sitrk_t *h, int slot, const void *slab_dev)
@@ -381,8 +484,28 @@ SITRK_API int sitrk_push_record_dev(sitrk_t *h, int slot, const void *slab_dev)
     NEED(slab_dev, "sitrk_push_record_dev: null slab");
     HIPCHK(hipSetDevice(h->device));
     void *d = slab_of(h, slot);
+    int rc = slot_wait_upload(h, slot);
+    if (rc) return rc;
     if (d != slab_dev) HIPCHK(hipMemcpyAsync(d, slab_dev, h->slab_bytes, hipMemcpyDeviceToDevice, h->stream));
+    h->slot_row_lo[slot] = 0; h->slot_row_hi[slot] = h->Nj;
     return derive_mask(h, slot);
+}
+
+// A slot that holds only a band of rows may be stepped with only while every live buoy is provably inside the band:
+// [jmin-2-age, jmax+3+age) with (jmin,jmax) from the last sitrk_buoy_rows() and age = records stepped since.
+static int check_band(sitrk_ctx *h, int slot, int extra_age)
+{
+    const int lo = h->slot_row_lo[slot], hi = h->slot_row_hi[slot];
+    if (lo == 0 && hi == h->Nj) return SITRK_OK;
+    if (h->band_age < 0)
+        return fail(h, SITRK_EINVAL, "slot %d holds rows [%d,%d) only: call sitrk_buoy_rows() after sitrk_set_buoys() so that the band can be checked", slot, lo, hi);
+    if (h->band_jmin > h->band_jmax) return SITRK_OK;       // no live buoy
+    const int age = h->band_age + extra_age;
+    const int need_lo = std::max(0, h->band_jmin - 2 - age), need_hi = std::min(h->Nj, h->band_jmax + 3 + age);
+    if (lo > need_lo || hi < need_hi)
+        return fail(h, SITRK_EINVAL, "slot %d holds rows [%d,%d) but the buoys (rows %d..%d, %d records ago) can touch rows [%d,%d)",
+                    slot, lo, hi, h->band_jmin, h->band_jmax, age, need_lo, need_hi);
+    return SITRK_OK;
 }
 
 // --------------------------------------------------------------------------- buoys
@@ -399,6 +522,7 @@ SITRK_API int sitrk_set_buoys(sitrk_t *h, int64_t nP, const double *yx, const in
     free_buoys(h);
     h->windowed = (rec_first != nullptr);
     h->cur = 0; h->steps_since_sort = 0; h->sorted_once = false;
+    h->band_age = -1;
     // host-side validation + packing of the host cell
     std::vector<int32_t> packed;
     try {
@@ -524,14 +648,18 @@ SITRK_API int sitrk_step(sitrk_t *h, int slot, int jrec)
     NEED(h->slabs, "sitrk_step: call sitrk_alloc_records first");
     NEED(slot >= 0 && slot < h->nslots, "sitrk_step: slot out of range");
     if (h->nP == 0) return SITRK_OK;
+    int rc = check_band(h, slot, 0);
+    if (rc) return rc;
     if (h->resort_every > 0 && h->steps_since_sort >= h->resort_every) {
-        int rc = sitrk_sort_buoys(h);
+        rc = sitrk_sort_buoys(h);
         if (rc) return rc;
     }
     if (h->slot_dirty[slot]) {            // slab written through sitrk_record_ptr and not committed yet
-        int rc = derive_mask(h, slot);
+        rc = derive_mask(h, slot);
         if (rc) return rc;
     }
+    rc = slot_wait_upload(h, slot);
+    if (rc) return rc;
     const size_t n = (size_t)h->Nj * h->Ni, es = elem_size(h->dtype);
     const char *slab = slab_of(h, slot);
     BuoyState &s = h->st[h->cur];
@@ -544,7 +672,11 @@ SITRK_API int sitrk_step(sitrk_t *h, int slot, int jrec)
     if (h->dtype == SITRK_F64) launch_step<double>(h, a);
     else launch_step<float>(h, a);
     HIPCHK(hipGetLastError());
+    rc = launch_mark(h, &slot, 1);
+    if (rc) return rc;
     h->steps_since_sort++;
+    h->n_step_launches++;
+    if (h->band_age >= 0) h->band_age++;
     return SITRK_OK;
 }
 
@@ -600,21 +732,42 @@ SITRK_API int sitrk_run(sitrk_t *h, int slot0, int jrec0, int nsteps)
         ra.s.rdt = h->rdt; ra.s.rmin_conc = h->rmin_conc; ra.s.eps_mg = h->eps_mg; ra.s.geo = h->geo; ra.s.orient = h->orient; ra.s.kill = nullptr; ra.s.u = ra.s.v = nullptr;
         ra.s.pos = s.pos; ra.s.cell = s.cell; ra.s.kill_rec = s.kill_rec; ra.s.first = s.first; ra.s.last = s.last;
         ra.nrec = m;
+        int used[kMaxFuse];
         for (int r = 0; r < m; r++) {
             const int slot = (slot0 + k + r) % h->nslots;
+            used[r] = slot;
+            int rc = check_band(h, slot, r);
+            if (rc) return rc;
             if (h->slot_dirty[slot]) {
-                int rc = derive_mask(h, slot);
+                rc = derive_mask(h, slot);
                 if (rc) return rc;
             }
+            rc = slot_wait_upload(h, slot);
+            if (rc) return rc;
             const char *slab = slab_of(h, slot);
             ra.u[r] = slab; ra.v[r] = slab + n * es; ra.kill[r] = h->kill + (size_t)slot * n;
         }
         if (h->dtype == SITRK_F64) launch_run<double>(h, ra);
         else launch_run<float>(h, ra);
         HIPCHK(hipGetLastError());
+        int rc = launch_mark(h, used, m);
+        if (rc) return rc;
         h->steps_since_sort += m;
+        h->n_fused_launches++;
+        h->n_fused_records += m;
+        if (h->band_age >= 0) h->band_age += m;
         k += m;
     }
+    return SITRK_OK;
+}
+
+SITRK_API int sitrk_launch_stats(sitrk_t *h, int reset, int64_t *fused_launches, int64_t *fused_records, int64_t *step_launches)
+{
+    NEED(h, "null handle");
+    if (fused_launches) *fused_launches = h->n_fused_launches;
+    if (fused_records) *fused_records = h->n_fused_records;
+    if (step_launches) *step_launches = h->n_step_launches;
+    if (reset) h->n_fused_launches = h->n_fused_records = h->n_step_launches = 0;
     return SITRK_OK;
 }
 

@@ -30,7 +30,18 @@ struct sitrk_ctx {
 
     hipStream_t own_stream = nullptr;   // created by the library
     hipStream_t stream = nullptr;       // compute stream in use (own or adopted)
+    hipStream_t copy_stream = nullptr;  // host -> device record uploads (overlap with stepping)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // record ingest: library-owned pinned staging, double-buffered (sitrk_stage_acquire / sitrk_stage_submit).
+    // The caller's buffers are copied (or read by the caller) into pinned memory before a push returns, the DMA into
+    // the slot runs on copy_stream, ordered against the compute stream by events only.
+    static constexpr int kStage = 2;
+    void *stage[kStage] = {nullptr, nullptr};
+    size_t stage_bytes = 0;                     // capacity of each buffer (= one whole slab)
+    hipEvent_t stage_done[kStage] = {nullptr, nullptr};   // recorded on copy_stream behind the last DMA out of the buffer
+    int stage_next = 0;                         // buffer the next acquire hands out
+    int stage_rows = -1;                        // rows of the buffer handed out by acquire and not submitted yet (-1: none)
 
     // grid
     int Nj = 0, Ni = 0;
@@ -56,6 +67,23 @@ struct sitrk_ctx {
     void *slabs = nullptr;              // nslots * [u|v|sic]
     int8_t *kill = nullptr;             // nslots * (Nj*Ni) Survive masks derived from (tmask, sic, rmin_conc)
     unsigned char slot_dirty[4096] = {0};   // slab (re)written since its mask was derived
+    // per slot: upload still in flight on copy_stream (the compute stream waits for slot_ready before it reads the
+    // slot; events are created on first use), and the sequence number of the last launch that reads the slot (an upload
+    // into it waits for that launch's event in the ring below, not for the whole compute stream)
+    unsigned char slot_pending[4096] = {0};
+    hipEvent_t slot_ready[4096] = {nullptr};
+    long long slot_used_seq[4096];
+    static constexpr int kLaunchRing = 64;
+    hipEvent_t launch_ev[kLaunchRing] = {nullptr};
+    long long launch_seq = 0;
+    // rows [row_lo,row_hi) of the slot's u,v hold this record (whole record: 0..Nj); everything else is stale.
+    // Survive bytes are valid for rows (row_lo, row_hi-1) and the domain rim.
+    int slot_row_lo[4096] = {0}, slot_row_hi[4096] = {0};
+    // host rows of the live buoys at the last sitrk_buoy_rows(), and the records stepped since (a host cell moves
+    // at most one row per record): what a partly uploaded slot is checked against
+    int band_jmin = 0, band_jmax = -1, band_age = -1;      // band_age < 0: not evaluated since sitrk_set_buoys
+    // launch accounting (sitrk_launch_stats)
+    long long n_fused_launches = 0, n_fused_records = 0, n_step_launches = 0;
 
     // buoys
     int64_t nP = 0;

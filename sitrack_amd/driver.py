@@ -56,6 +56,9 @@ def parse_args(argv=None):
     ap.add_argument('--device', type=int, default=0, help='GPU to use (extra)')
     ap.add_argument('--uv-strategy', type=int, default=1, choices=(0, 1, 2),
                     help='iUVstrategy of the reference (0 cell mean, 1 nearest U/V point = default); 2 = linear interpolation, an extra the reference does not have')
+    ap.add_argument('--slots', type=int, default=32,
+                    help='model records resident on the GPU (extra): up to half of them are advanced by one fused launch '
+                         'whenever no per-record output is due, while the next ones are read and uploaded')
     ap.add_argument('--full-records', action='store_true',
                     help='read and upload whole records (under torchrun: rank 0 reads, RCCL broadcast) instead of only the rows '
                          'each rank\'s buoys can touch (extra; same results)')
@@ -242,7 +245,8 @@ def main(argv=None):
 
     (u0,) = records.fields(kstrt, ('u_ice',))
     fdt = np.float64 if np.asarray(u0).dtype == np.float64 else np.float32
-    trk = IceTracker(xYf, xXf, xYu, xXu, xYv, xXv, imaskt, rdt=rdt, iUVstrategy=iUVstrategy, nslots=1, field_dtype=fdt, ctx=ctx)
+    K = int(max(2, min(a.slots, 64)))
+    trk = IceTracker(xYf, xXf, xYu, xXu, xYv, xXv, imaskt, rdt=rdt, iUVstrategy=iUVstrategy, nslots=K, field_dtype=fdt, ctx=ctx)
     trk.set_buoys(xPosC0[mine], vJIt[mine], z1stModelRec[mine] if lUse2DTime else None, zLstModelRec[mine] if lUse2DTime else None)
 
     # ---- host arrays (rank 0): the full series only when it is written
@@ -268,23 +272,65 @@ def main(argv=None):
             if np.any(late):
                 z2GC[0, late] = ctx.cart2geo(xPosC0[late])
 
-    # ---- the record loop (:361-496)
-    for jt in range(Nt):
-        jrec = jt + kstrt
-        itmod = records.time(jrec)
-        itime = itmod - int(rdt / 2.)
-        vTime[jt] = itime
-        nalive = comm.sum_int(trk.alive_count())
-        say(' *** record #%d/%d  date = %s   buoys alive = %d' % (jrec + 1, Nt0, epoch2clock(itime), nalive))
+    # ---- the record loop (:361-496).  The reference steps record by record; here consecutive records go through ONE
+    #      fused launch (sitrk_run: every buoy still takes every step, only the loop nest is interchanged) whenever no
+    #      per-record output is due between them -- always in the default 2-D-time mode, which writes first/last positions
+    #      only (:565-571).  Records are read straight into the library's pinned staging and uploaded on its copy stream
+    #      while the previous batch is stepped with; `-F` / `-p` need every record's positions: batches of one.
+    def need_output(jrec):
+        return lFull or (lUse2DTime and jrec in ends)
+
+    batches, jt = [], 0
+    while jt < Nt:
+        m = 1
+        while m < K // 2 and jt + m < Nt and not need_output(jt + m - 1 + kstrt):
+            m += 1
+        batches.append((jt, m))
+        jt += m
+    band = {"jmin": 0, "jmax": -1, "age": None}
+
+    def upload(jt0, m):
+        """records jt0..jt0+m-1 -> slots (jt0+r) % K, asynchronously"""
         if not a.full_records:
-            j0, j1 = trk.band()                                         # rows this rank's buoys can touch in this record
-            trk.load_record_rows(0, j0, j1, *records.fields_rows(jrec, j0, j1))
-        elif comm.world == 1:
-            trk.load_record(0, *records.fields(jrec))                   # the whole record (:372-374)
+            # rows this rank's buoys can touch during those records: the host rows at the last evaluation, widened by one
+            # row per record stepped or queued since (sitrk_buoy_rows waits for the GPU: only every so often)
+            if band["age"] is None or band["age"] + m > 96:
+                band["jmin"], band["jmax"] = ctx.buoy_rows()
+                band["age"] = 0
+            w = band["age"] + m - 1
+            j0, j1 = (0, 0) if band["jmin"] > band["jmax"] else (max(0, band["jmin"] - 2 - w), min(Nj, band["jmax"] + 3 + w))
+            band["age"] += m
+        for r in range(m):
+            jrec, slot = jt0 + r + kstrt, (jt0 + r) % K
+            if not a.full_records:
+                if j1 > j0:
+                    records.fields_rows_into(jrec, j0, j1, ctx.stage(j1 - j0))
+                    ctx.submit(slot, j0)
+                else:
+                    ctx.commit_record_rows(slot, 0, 0)                  # no live buoy: nothing to read
+            elif comm.world == 1:
+                records.fields_rows_into(jrec, 0, Nj, ctx.stage(Nj))   # the whole record (:372-374)
+                ctx.submit(slot, 0)
+            else:
+                comm.deliver_record(ctx, slot, records.fields(jrec) if comm.root else None)   # rank 0 reads, RCCL broadcast
+
+    if batches:
+        upload(*batches[0])
+    for ib, (jt0, m) in enumerate(batches):
+        jrec0, jrecN = jt0 + kstrt, jt0 + m - 1 + kstrt
+        for r in range(m):
+            vTime[jt0 + r] = records.time(jrec0 + r) - int(rdt / 2.)
+        if m == 1:
+            nalive = comm.sum_int(trk.alive_count())
+            say(' *** record #%d/%d  date = %s   buoys alive = %d' % (jrec0 + 1, Nt0, epoch2clock(vTime[jt0]), nalive))
         else:
-            comm.deliver_record(ctx, 0, records.fields(jrec) if comm.root else None)   # rank 0 reads, RCCL broadcast
-        trk.step(jrec, 0)
-        need = lFull or (lUse2DTime and jrec in ends)
+            say(' *** records #%d..#%d/%d  dates = %s .. %s   (one fused launch)' % (jrec0 + 1, jrecN + 1, Nt0, epoch2clock(vTime[jt0]),
+                                                                                   epoch2clock(vTime[jt0 + m - 1])))
+        trk.run(jrec0, jt0 % K, m)
+        if ib + 1 < len(batches):
+            upload(*batches[ib + 1])               # travels while the launch above runs
+        jt, jrec, itime = jt0 + m - 1, jrecN, vTime[jt0 + m - 1]
+        need = need_output(jrec)
         if need:
             pos_l, msk_l = trk.record(jrec)
             pos, msk = to_caller_order(comm.gather_rows(pos_l, nP)), to_caller_order(comm.gather_rows(msk_l, nP))

@@ -136,6 +136,17 @@ class H5File:
             raise TypeError("%s: unsupported numeric type %s" % (what, key))
         return key
 
+    def dtype(self, name):
+        """numpy dtype the dataset `name` is stored with"""
+        d = self._open(name)
+        try:
+            tid = self.L.H5Dget_type(d)
+            key = self._npkind(tid, name)
+            self.L.H5Tclose(tid)
+            return np.dtype(key)
+        finally:
+            self.L.H5Dclose(d)
+
     def shape(self, name):
         d = self._open(name)
         try:
@@ -149,13 +160,19 @@ class H5File:
         finally:
             self.L.H5Dclose(d)
 
-    def read(self, name, index=Ellipsis):
+    def read(self, name, index=Ellipsis, out=None):
         """numpy array of dataset `name`.  `index`: Ellipsis, an int, a slice (step 1) or a tuple of those for the
-        leading dimensions -> one hyperslab read; anything else is applied with numpy after reading everything."""
+        leading dimensions -> one hyperslab read; anything else is applied with numpy after reading everything.
+        `out` (optional): a C-contiguous numeric array of the selection's shape to read INTO (HDF5 converts to its
+        dtype) -- e.g. pinned staging memory of libsitrk, so that a record goes from the file to DMA-able memory in one
+        pass; only for hyperslab selections."""
         shp = self.shape(name)
         idx = index if isinstance(index, tuple) else (index,)
         simple = all(isinstance(k, (int, np.integer)) or k is Ellipsis or (isinstance(k, slice) and k.step in (None, 1)) for k in idx)
         if not simple or sum(k is Ellipsis for k in idx) > 1 or (Ellipsis in idx and idx[-1] is not Ellipsis):
+            if out is not None:
+                out[...] = self.read(name)[index]
+                return out
             return self.read(name)[index]
         idx = tuple(k for k in idx if k is not Ellipsis)
         if len(idx) > len(shp):
@@ -177,7 +194,14 @@ class H5File:
             tid = self.L.H5Dget_type(d)
             key = self._npkind(tid, name)
             self.L.H5Tclose(tid)
-            out = np.empty(out_shape, dtype=np.dtype(key))
+            if out is None:
+                out = np.empty(out_shape, dtype=np.dtype(key))
+            else:
+                if tuple(out.shape) != out_shape or not out.flags.c_contiguous:
+                    raise ValueError("%s: `out` must be C-contiguous of shape %s, got %s" % (name, out_shape, tuple(out.shape)))
+                key = out.dtype.kind + str(out.dtype.itemsize)           # memory type: HDF5 converts on the fly
+                if key not in self.L._native or not out.dtype.isnative:
+                    raise TypeError("%s: cannot read into dtype %s" % (name, out.dtype))
             if out.size == 0:
                 return out
             nd = len(shp)

@@ -299,6 +299,19 @@ class ModelRecords:
         """rows [j0,j1) only (row-band ingest: a rank reads just the rows its buoys can touch)"""
         return tuple(self.f.var(n, (jrec, slice(j0, j1))) for n in names)
 
+    def fields_rows_into(self, jrec, j0, j1, outs, names=('u_ice', 'v_ice', 'siconc')):
+        """Rows [j0,j1) of record `jrec` read INTO the arrays `outs` (libsitrk's pinned staging: file -> DMA-able memory
+        in one pass through libhdf5; other backends assign).  Values must survive the cast to the outs' dtype exactly."""
+        for n, out in zip(names, outs):
+            packed = self.f.has_attr(n, 'scale_factor') or self.f.has_attr(n, 'add_offset')
+            if self.f.h5 is not None and not packed and self.f.h5.dtype(n).itemsize <= out.dtype.itemsize:
+                self.f.h5.read(n, (jrec, slice(j0, j1)), out=out)
+                continue
+            a = np.asarray(self.f.var(n, (jrec, slice(j0, j1))))
+            if a.dtype.newbyteorder('=') != out.dtype and not np.array_equal(a.astype(out.dtype).astype(a.dtype), a, equal_nan=True):
+                raise ValueError("%s is not exactly representable as %s; allocate float64 records" % (n, out.dtype))
+            out[...] = a
+
     def close(self):
         self.f.close()
 

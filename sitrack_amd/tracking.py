@@ -186,6 +186,14 @@ class IceTracker:
     def step(self, jrec, slot=0):
         self.ctx.step(slot, jrec)
 
+    def run(self, jrec0, slot0, nrec):
+        """records jrec0 .. jrec0+nrec-1 from slots (slot0+k) % nslots: one fused launch where the library can
+        (sitrk_run), same results as nrec calls of step()"""
+        if nrec == 1:
+            self.ctx.step(slot0, jrec0)
+        else:
+            self.ctx.run(slot0, jrec0, nrec)
+
     def record(self, jrec, latlon=False):
         return self.ctx.fetch_record(jrec, latlon=latlon)
 

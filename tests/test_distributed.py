@@ -183,7 +183,7 @@ def test_bench_two_ranks_as_the_driver_launches_it():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--e2e-full"]])
+@pytest.mark.parametrize("extra", [[], ["--e2e-full"], ["--e2e-library"], ["--e2e-library", "--e2e-full"]])
 def test_bench_end_to_end_regime_checks_against_the_oracle(extra):
     """bench.py --regime e2e (every record uploaded from pinned host memory on a copy stream, double-buffered against the
     stepping on a second stream, row bands or whole records): the run's own --check replays it on the oracle."""
@@ -199,4 +199,4 @@ def test_bench_end_to_end_regime_checks_against_the_oracle(extra):
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["config"]["regime"] == "e2e" and d["value"] > 0 and d["config"]["e2e_upload_bytes_per_step"] > 0
     full = 3 * 512 * 512 * 4
-    assert (d["config"]["e2e_upload_bytes_per_step"] == full) == bool(extra)
+    assert (d["config"]["e2e_upload_bytes_per_step"] == full) == ("--e2e-full" in extra)

@@ -167,9 +167,11 @@ def _write_h5_like_nc3(fname, dims, variables, attrs=None):
     h5write.write_h5(fname, vv, dims=dl)
 
 
-def make_case(tmp, nrec=14, nP=300, two_d_time=False, Nj=60, Ni=70, dkm=10.0, fmt="nc3"):
+def make_case(tmp, nrec=14, nP=300, two_d_time=False, Nj=60, Ni=70, dkm=10.0, fmt="nc3", ice_mask_seeding=False):
     """Synthetic NANUK-like inputs: mesh_mask, icemod (hourly), seeding file -- as NetCDF-3 files, or (fmt="hdf5") as
-    HDF5 files laid out like the NetCDF-4 files NEMO and the reference's seeding tools write."""
+    HDF5 files laid out like the NetCDF-4 files NEMO and the reference's seeding tools write.
+    ice_mask_seeding: keep only the random seeds whose nearest T-point `nemoSeed` (reference tracking.py:365-442) would
+    seed: tmask = 1, latitude >= 55, siconc >= 0.9 at the first record."""
     from oracle import oracle as orc
     _write_nc3 = globals()["_write_nc3"] if fmt == "nc3" else _write_h5_like_nc3
     g = syn.make_grid(Nj, Ni, dkm=dkm, warp=1.0)
@@ -179,6 +181,8 @@ def make_case(tmp, nrec=14, nP=300, two_d_time=False, Nj=60, Ni=70, dkm=10.0, fm
         g[k] = g[k] + 150.
     ll = {p: orc.CartNPSkm2Geo1D(np.stack([g["Y" + p].ravel(), g["X" + p].ravel()], axis=1)) for p in "tufv"}
     tmask = g["tmask"].copy(); tmask[25:30, 40:46] = 0
+    if Nj > 200:                                       # larger meshes: an island of proportionate size
+        tmask[Nj // 3:Nj // 3 + Nj // 12, Ni // 2:Ni // 2 + Ni // 10] = 0
     mm = os.path.join(tmp, "mesh_mask_TEST4.nc")
     var = {"tmask": ('i1', ('t', 'z', 'y', 'x'), tmask[None, None], None),
            "e1t": ('f8', ('t', 'y', 'x'), np.full((1, Nj, Ni), dkm * 1000.), None),
@@ -190,6 +194,8 @@ def make_case(tmp, nrec=14, nP=300, two_d_time=False, Nj=60, Ni=70, dkm=10.0, fm
     base = 850608000
     u, v, sic = syn.make_fields(g, K=nrec, seed=77, umax=0.9, drift=0.3, ripple=0.1)
     sic[:, 10:16, 12:30] = 0.03
+    if Nj > 200:                                       # ... and a polynya
+        sic[:, Nj // 2:Nj // 2 + Nj // 10, Ni // 5:Ni // 5 + Ni // 6] = 0.03
     tc = (base + 1800 + 3600 * np.arange(nrec)).astype('i4')
     si3 = os.path.join(tmp, "TEST4-EXP01_1h_19961215_19961216_icemod.nc")
     _write_nc3(si3, {"time_counter": None, "y": Nj, "x": Ni},
@@ -199,6 +205,12 @@ def make_case(tmp, nrec=14, nP=300, two_d_time=False, Nj=60, Ni=70, dkm=10.0, fm
                 "v_ice": ('f4', ('time_counter', 'y', 'x'), v, None)})
     rng = np.random.default_rng(5)
     yx = np.stack([rng.uniform(g["Yt"].min() + 30, g["Yt"].max() - 30, nP), rng.uniform(g["Xt"].min() + 30, g["Xt"].max() - 30, nP)], axis=1)
+    if ice_mask_seeding:
+        jiN = syn.nearest_t_plane(g, yx)
+        latT = ll["t"][:, 0].reshape(Nj, Ni)
+        ok = (tmask[jiN[:, 0], jiN[:, 1]] == 1) & (latT[jiN[:, 0], jiN[:, 1]] >= 55.) & (sic[0][jiN[:, 0], jiN[:, 1]] >= 0.9)
+        yx = yx[ok]
+        nP = len(yx)
     sll = orc.CartNPSkm2Geo1D(yx)
     ids = (300534062025510 + 7 * np.arange(nP)).astype(np.int64)
     seed = os.path.join(tmp, "sitrack_seeding_nemoTsi3_19961215_00_HSS5.nc")

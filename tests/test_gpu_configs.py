@@ -1,0 +1,150 @@
+"""Every BASELINE.json configuration SHAPE on the GPU (`pytest -m gpu`), as far as one GPU and this image allow:
+
+* C2  (512x512, 1e5 buoys)  at its full 1000 steps, resident regime, `bench.py --check` = the oracle replays the run;
+* C3  (4096x4096, 1e7 buoys) at its full 1000 steps, same check (24-step property tests: test_gpu_fullsize.py);
+* C4  (4096x4096, 1e8 buoys over 8 GPUs): the per-rank shard (1.25e7 buoys) of ranks 0 and 7 through the fused path with
+  the oracle on a subsample, and two adjacent shards in one context == the two shards separately (the partition
+  invariance the 8-GPU run relies on).  The 8-GPU run itself is the driver's to launch;
+* C5  (NANUK4 mesh, 1e7 buoys under the ice mask): the command line on a NANUK4-SHAPED synthetic mesh (566 x 492 at
+  12.5 km -- the real mesh_mask and the demo tarball are not in the container), >= 1e6 seeds placed under a synthetic
+  ice mask by `nemoSeed`'s rule, the reference's default 2-D-time mode, diffed against the oracle on a subsample;
+* C1  (NANUK4 demo, 986 buoys, CPU reference path) cannot run here: tarball, netCDF4 and mojito are absent.
+"""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import sitrack_amd as sit
+from sitrack_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args, timeout=1500):
+    r = subprocess.run([sys.executable, "bench.py"] + args, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]), r.stderr
+
+
+def test_c2_full_1000_steps_checked_by_the_oracle():
+    d, err = _bench(["--config", "c2", "--steps", "1000", "--warmup", "50", "--check", "--no-cpu-baseline"])
+    assert "check OK" in err, err[-2000:]
+    assert d["steps"] == 1000 and d["config"]["grid"] == [512, 512] and d["config"]["buoys_per_gpu"] == 100000
+    r = d["roofline"]
+    # what the line says about its launches is what the library launched
+    assert r["launches"] + r["one_record_launches"] >= 1000 // 32 and r["records_advanced"] + r["one_record_launches"] == 1000
+
+
+def test_c3_full_1000_steps_checked_by_the_oracle():
+    """the headline workload at the length BASELINE quotes it: 1e7 buoys x 1000 records (+ the two reference legs of the
+    same run), first 20 000 buoys bit-exact against the oracle at the end"""
+    d, err = _bench(["--steps", "1000", "--warmup", "50", "--check", "--no-cpu-baseline", "--no-c2"])
+    assert "check OK" in err, err[-2000:]
+    assert d["config"]["grid"] == [4096, 4096] and d["config"]["buoys_per_gpu"] == 10_000_000 and d["value"] > 1e9
+    r = d["roofline"]
+    assert r["bound"] == "fp64_valu_issue" and r["records_advanced"] + r["one_record_launches"] == 1000
+    # frac follows from the line's own numbers
+    want = r["valu_inst_per_wave_record"] * r["waves_per_launch"] * (r["records_advanced"] + r["one_record_launches"]) / \
+        (r["avg_launch_ms"] * 1e-3 * (r["launches"] + r["one_record_launches"])) / 1e9 / r["peak"]
+    assert abs(r["frac"] - want) < 1e-6 * want
+
+
+@pytest.fixture(scope="module")
+def c4():
+    from bench import CONFIGS
+    Nj, Ni, nP, _ = CONFIGS["c4"]
+    assert (Nj, Ni, nP) == (4096, 4096, 12_500_000)
+    K = 6
+    grid = syn.make_grid(Nj, Ni, dkm=4.0, warp=0.0)
+    u, v, sic = syn.make_fields(grid, K=K, seed=2024, umax=0.3, drift=0.05)
+    sic[:, 2000:2080, 1400:1700] = 0.02                 # open water: some buoys of every shard die
+    return dict(grid=grid, u=u, v=v, sic=sic, K=K, nP=nP)
+
+
+def _shard(c4, rank):
+    """rank r's buoys exactly as bench.py --gpus 8 seeds them"""
+    _, yx = syn.make_buoys(c4["grid"], c4["nP"], seed=1234 + rank, frac=0.6)
+    return yx, syn.regular_host_cell(c4["grid"], yx).astype(np.int32)
+
+
+def _run(c4, yx, ji, nsteps):
+    g = c4["grid"]
+    ctx = sit.Context(0)
+    try:
+        ctx.set_grid(g["Yf"], g["Xf"], g["Yu"], g["Xu"], g["Yv"], g["Xv"], g["tmask"])
+        ctx.alloc_records(c4["K"], np.float32)
+        for k in range(c4["K"]):
+            ctx.push_record(k, c4["u"][k], c4["v"][k], c4["sic"][k])
+        ctx.set_buoys(yx, ji)
+        ctx.run(0, 0, nsteps)
+        return ctx.fetch()
+    finally:
+        ctx.close()
+
+
+def test_c4_rank_shards_and_partition_invariance(c4):
+    from oracle import oracle as orc
+    nsteps = 30
+    f64 = [(c4["u"][k].astype(np.float64), c4["v"][k].astype(np.float64), c4["sic"][k].astype(np.float64)) for k in range(c4["K"])]
+    shards, outs = {}, {}
+    for rank in (0, 1, 7):
+        shards[rank] = _shard(c4, rank)
+        outs[rank] = _run(c4, *shards[rank], nsteps)
+    for rank in (0, 7):                                  # the oracle on every 1201st buoy of the first and last rank
+        yx, ji = shards[rank]
+        sel = np.arange(0, len(yx), 1201)
+        ref = orc.Tracker(c4["grid"], yx[sel], ji[sel], nthreads=8)
+        for s in range(nsteps):
+            ref.step(s, *f64[s % c4["K"]], want_out=False)
+        o = outs[rank]
+        assert np.array_equal(o["yx"][sel], ref.pos) and np.array_equal(o["jiT"][sel], ref.jiT)
+        assert np.array_equal(o["alive"][sel], ref.alive) and 0 < o["alive"].sum() < len(yx)
+    # two adjacent shards in ONE context == each on its own (2.5e7 buoys on one GPU)
+    both = _run(c4, np.concatenate([shards[0][0], shards[1][0]]), np.concatenate([shards[0][1], shards[1][1]]), nsteps)
+    for k in ("yx", "jiT", "alive", "kill_rec"):
+        assert np.array_equal(both[k], np.concatenate([outs[0][k], outs[1][k]])), k
+
+
+def test_c5_shape_cli_on_a_nanuk4_shaped_mesh(tmp_path, monkeypatch):
+    """NANUK4-SHAPED, not NANUK4: synthetic 566 x 492 mesh at 12.5 km, hourly records, >= 1e6 seeds under a synthetic ice
+    mask (a seed is kept where `nemoSeed` would seed its nearest T-point: tmask = 1, lat >= 55, siconc >= 0.9), the
+    reference's default 2-D-time mode with late starters / early stoppers.  The command line runs files in -> files
+    out; every 997th kept buoy is replayed on the oracle from the seed cache the run wrote."""
+    import test_driver as td
+    from oracle import oracle as orc
+    from sitrack_amd import driver as drv, ncio
+    monkeypatch.chdir(tmp_path)
+    nrec = 40
+    c = td.make_case(str(tmp_path), nrec=nrec, nP=1_300_000, Nj=566, Ni=492, dkm=12.5, two_d_time=True, ice_mask_seeding=True)
+    assert len(c["ids"]) >= 1_000_000
+    out = drv.main(["-i", c["si3"], "-m", c["mm"], "-s", c["seed"], "-N", "TEST4"])
+    with np.load(glob.glob("./seed/Initialized_buoys_*.npz")[0]) as z:
+        nP, xPosC0, vJIt0, keep = int(z["nP"]), z["xPosC0"], z["vJIt"], z["idxKeep"]
+    assert nP == out["nP"] and nP > 900_000
+    imaskt, _, _, _, _, xYf, xXf, _ = ncio.GetModelGrid(c["mm"])
+    xYv, xXv, xYu, xXu = ncio.GetModelUVGrid(c["mm"])
+    grid = dict(Yf=xYf, Xf=xXf, Yu=xYu, Xu=xXu, Yv=xYv, Xv=xXv, tmask=imaskt)
+    tc, base, n0 = c["tc"], c["base"], len(c["ids"])
+    tp0 = np.full(n0, base); tp0[::7] = base + 4 * 3600
+    tp1 = np.full(n0, tc[-1] + 1800); tp1[::5] = base + 9 * 3600
+    z1, zL = drv.record_windows(np.stack([tp0, tp1]), tc, 0, len(tc) - 1, tc[0], tc[-1], n0)
+    z1, zL = z1[keep], zL[keep]
+    sub = np.arange(0, nP, 997)
+    ref = orc.Tracker(grid, xPosC0[sub], vJIt0[sub], rec_first=z1[sub], rec_last=zL[sub], nthreads=8)
+    last = xPosC0[sub].copy()
+    for jt in range(len(tc)):
+        pn, mn = ref.step(jt, c["u"][jt].astype('f8'), c["v"][jt].astype('f8'), c["sic"][jt].astype('f8'))
+        last[mn == 1] = pn[mn == 1]
+    assert np.array_equal(out["vJIt"][sub], ref.jiT) and np.array_equal(out["iAlive"][sub], ref.alive)
+    assert 0 < (ref.alive == 0).sum() < len(sub)                         # some die, most live
+    _, ids2, _, yx2, mk2 = ncio.LoadNCdata(out["files"][0], krec=-1, lmask=True)
+    assert np.array_equal(ids2, out["IDs"])
+    ok = mk2[1][sub] == 1
+    assert ok.sum() > 0.5 * len(sub)
+    assert np.array_equal(yx2[1][sub][ok].astype('f4'), last[ok].astype('f4'))

@@ -412,6 +412,97 @@ def test_row_band_ingest_equals_full_ingest(fdt):
         assert np.array_equal(res["band"][key], res["full"][key]), key
     assert not np.isnan(res["band"]["yx"]).any() and 0 < res["band"]["iAlive"].sum() < len(res["band"]["iAlive"])
 
+def test_async_ingest_ring_and_staging():
+    """Library-owned ingest (include/sitrk.h: pinned staging, copy stream, events): records are pushed from TEMPORARY host
+    arrays that are scribbled over right after the call, pushed two batches ahead of the launches that use them, read
+    straight into the pinned staging, and a slot is re-uploaded while the launch that used it may still be running --
+    the trajectories equal the oracle's record by record."""
+    Nj, Ni, K, Nt = 96, 120, 8, 64
+    grid = syn.make_grid(Nj, Ni, dkm=4.0, warp=1.0)
+    u, v, sic = syn.make_fields(grid, K=Nt, seed=5, umax=0.9, drift=0.4, ripple=0.1)
+    sic[:, 30:40, 50:80] = 0.04
+    _, yx = syn.make_buoys(grid, 40000, seed=8, frac=0.8)
+    trk = make_tracker(grid, grid["tmask"], K)
+    try:
+        found, ji, _ = sit.FindContainingCell(yx, syn.nearest_t_plane(grid, yx), ctx=trk.ctx)
+        yx, ji = yx[found], ji[found]
+        trk.set_buoys(yx, ji)
+        ref = orc.Tracker(grid, yx, ji, nthreads=4)
+        ctx = trk.ctx
+        ref_done[0] = 0
+
+        def upload(s):
+            if s % 3 == 0:                                  # through a temporary that is destroyed at once
+                tu, tv, ts = u[s].copy(), v[s].copy(), sic[s].copy()
+                ctx.push_record(s % K, tu, tv, ts)
+                tu[:] = np.nan; tv[:] = 1e30; ts[:] = 0.
+            elif s % 3 == 1:                                # straight into the library's pinned staging
+                bu, bv, bs = ctx.stage()
+                bu[...] = u[s]; bv[...] = v[s]; bs[...] = sic[s]
+                ctx.submit(s % K)
+            else:                                           # as a row band that happens to be the whole record
+                ctx.push_record_rows(s % K, 0, Nj, u[s], v[s], sic[s])
+        m = K // 2
+        for s in range(m):
+            upload(s)
+        for b in range(Nt // m):
+            ctx.run((b * m) % K, b * m, m)                  # asynchronous
+            if b + 1 < Nt // m:
+                for s in range((b + 1) * m, (b + 2) * m):   # overwrites the slots of batch b-1 while batch b runs
+                    upload(s)
+            if b % 3 == 2:
+                for s in range(max(0, b - 2) * m, (b + 1) * m):
+                    if s >= ref_done[0]:
+                        ref.step(s, u[s], v[s], sic[s], want_out=False)
+                        ref_done[0] = s + 1
+                st = trk.state()
+                assert np.array_equal(st["yx"], ref.pos) and np.array_equal(st["vJIt"], ref.jiT) and np.array_equal(st["iAlive"], ref.alive)
+        while ref_done[0] < Nt:
+            ref.step(ref_done[0], u[ref_done[0]], v[ref_done[0]], sic[ref_done[0]], want_out=False)
+            ref_done[0] += 1
+        st = trk.state()
+        assert np.array_equal(st["yx"], ref.pos) and np.array_equal(st["vJIt"], ref.jiT) and np.array_equal(st["iAlive"], ref.alive)
+        assert 0 < st["iAlive"].sum() < len(yx) and ref.ncross > 10000
+        stats = ctx.launch_stats()
+        assert stats["fused_records"] + stats["step_launches"] == Nt
+    finally:
+        trk.close()
+
+
+ref_done = [0]
+
+
+def test_partly_uploaded_slot_is_checked_against_the_buoys_band():
+    """a band that is too narrow must not silently read stale rows.  The library knows which rows of a slot are
+    valid and refuses a step whose buoys can reach outside them; untouched rows hold NaN velocities and kill bytes."""
+    Nj, Ni = 120, 64
+    grid = syn.make_grid(Nj, Ni, dkm=4.0, warp=0.0)
+    u, v, sic = syn.make_fields(grid, K=2, seed=2, umax=0.5)
+    _, yx = syn.make_buoys(grid, 5000, seed=4, frac=0.5)
+    trk = make_tracker(grid, grid["tmask"], 4)
+    try:
+        found, ji, _ = sit.FindContainingCell(yx, syn.nearest_t_plane(grid, yx), ctx=trk.ctx)
+        trk.set_buoys(yx[found], ji[found])
+        ctx = trk.ctx
+        jlo, jhi = int(ji[found][:, 0].min()), int(ji[found][:, 0].max())
+        ctx.push_record_rows(0, jlo - 2, jhi + 3, u[0][jlo - 2:jhi + 3], v[0][jlo - 2:jhi + 3], sic[0][jlo - 2:jhi + 3])
+        with pytest.raises(sit.SitrkError, match="sitrk_buoy_rows"):
+            ctx.step(0, 0)                                   # band never evaluated since set_buoys
+        assert ctx.buoy_rows() == (jlo, jhi)
+        ctx.step(0, 0)                                       # exactly the band: fine
+        with pytest.raises(sit.SitrkError, match="can touch rows"):
+            ctx.step(0, 1)                                   # one record later the band is one row too narrow on each side
+        # a fused run ages the band by one row per record: 3 records need 2 more rows than 1 record
+        ctx.set_buoys(yx[found], ji[found])
+        ctx.buoy_rows()
+        for k in range(3):
+            ctx.push_record_rows(k, jlo - 3, jhi + 4, u[k % 2][jlo - 3:jhi + 4], v[k % 2][jlo - 3:jhi + 4], sic[k % 2][jlo - 3:jhi + 4])
+        with pytest.raises(sit.SitrkError, match="can touch rows"):
+            ctx.run(0, 0, 3)
+        ctx.run(0, 0, 2)
+    finally:
+        trk.close()
+
 
 def test_run_many_steps_equals_stepping(ctx):
     grid = syn.make_grid(96, 96, dkm=4.0, warp=1.0)

@@ -27,6 +27,7 @@ def short(name):
 def main():
     src, tag = sys.argv[1], sys.argv[2]
     config = sys.argv[3] if len(sys.argv) > 3 else "c3"
+    rec_per_launch = int(sys.argv[4]) if len(sys.argv) > 4 else 32     # records every profiled fused dispatch advanced
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out_md = os.path.join(root, "profiles", "%s_%s_summary.md" % (tag, config))
     stats = {}
@@ -89,6 +90,11 @@ def main():
             res["valu_busy_frac"] = a["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / cyc
             if "SQ_INSTS_VALU" in a and "SQ_WAVES" in a:
                 res["valu_insts_per_wave"] = a["SQ_INSTS_VALU"] / a["SQ_WAVES"]
+                if fused:
+                    res["records_per_launch"] = rec_per_launch
+                    res["valu_per_wave_record"] = res["valu_insts_per_wave"] / rec_per_launch
+                    lines.append("SQ_INSTS_VALU / SQ_WAVES / %d records per launch = **%.1f VALU instructions per wave per record**."
+                                 % (rec_per_launch, res["valu_per_wave_record"]))
             lines.append("Instruction issue: SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs = %.0f cycles per SIMD of %.0f available "
                          "(GRBM_GUI_ACTIVE / 8) -> VALU busy %.0f %%; clock held %.2f GHz."
                          % (a["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0, cyc, 100 * res["valu_busy_frac"], res["sclk_ghz"]))
@@ -113,7 +119,9 @@ def main():
     allt = json.load(open(tj)) if os.path.exists(tj) else {}
     if "hbm_bytes_per_launch" in res:
         allt[config + "_fused" if fused else config] = {"hbm_bytes_per_launch": res["hbm_bytes_per_launch"], "source": os.path.basename(out_md),
-                                                        "valu_busy_frac": res.get("valu_busy_frac"), "sclk_ghz": res.get("sclk_ghz")}
+                                                        "valu_busy_frac": res.get("valu_busy_frac"), "sclk_ghz": res.get("sclk_ghz"),
+                                                        "valu_per_wave_record": res.get("valu_per_wave_record"),
+                                                        "records_per_launch": res.get("records_per_launch")}
         json.dump(allt, open(tj, "w"), indent=1)
     print("\n".join(lines))
 
