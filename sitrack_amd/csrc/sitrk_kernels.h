@@ -99,6 +99,35 @@ __global__ void survive_mask_rows_kernel(int Nj, int Ni, int j_lo, int j_hi, int
     kill[(size_t)j * Ni + i] = survive_kill<FT>(j, i, Nj, Ni, tmask, sic, rmin_conc) ? 1 : 0;
 }
 
+// The fused kernel reads ONE 16-bit word per crossing instead of three Survive bytes at computed addresses: bit
+// (dj+1)*3 + (di+1) of kill9[j,i] = Survive byte of cell (j+dj, i+di).  Packed from the byte mask for rows [j_lo, j_hi);
+// a row whose three byte rows are not all valid (valid = domain rim, or inside (v_lo, v_hi-1): see
+// survive_mask_rows_kernel) gets the sentinel "everything kills".
+__global__ void pack_kill9_kernel(int Nj, int Ni, int j_lo, int j_hi, int v_lo, int v_hi, const int8_t *__restrict__ kill,
+                                  uint16_t *__restrict__ kill9)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)(j_hi - j_lo) * Ni) return;
+    const int j = j_lo + (int)(t / (size_t)Ni), i = (int)(t % (size_t)Ni);
+    unsigned w = 0x1ffu;
+    bool ok = (j >= 1 && j <= Nj - 2 && i >= 1 && i <= Ni - 2);
+    for (int dj = -1; dj <= 1 && ok; dj++) {
+        const int r = j + dj;
+        const bool rim = (r <= 1 || r >= Nj - 2);
+        ok = rim || (r - 1 >= v_lo && r + 1 < v_hi);
+    }
+    if (ok) {
+        w = 0;
+        const size_t k = (size_t)j * Ni + i;
+#pragma unroll
+        for (int dj = -1; dj <= 1; dj++)
+#pragma unroll
+            for (int di = -1; di <= 1; di++)
+                w |= (kill[k + (ptrdiff_t)dj * Ni + di] ? 1u : 0u) << ((dj + 1) * 3 + (di + 1));
+    }
+    kill9[(size_t)j * Ni + i] = (uint16_t)w;
+}
+
 // rows of the host cells of the buoys that are still alive: out[0] = min jT, out[1] = max jT
 __global__ __launch_bounds__(kBlock) void buoy_rows_kernel(int64_t n, const int32_t *__restrict__ cell, int *out)
 {
@@ -187,6 +216,91 @@ __device__ __forceinline__ int32_t resolve_crossing(pt P1, pt P2, pt bl, pt br, 
     return cn;
 }
 
+
+// ---------------------------------------------------------------------------
+// The same chain for the fused kernel, driven by a 4-row table in LDS (one row per crossed edge) instead of chains of
+// selects and index arithmetic: the crossing path runs in every wave on every record with ~9 of 64 lanes active, so
+// every instruction in it is paid in full.  Everything memory-side is an offset from the host cell's own geometry
+// record (the F-point is its first member) or from its cell index; cells with jT < 2 or iT < 2, where numpy's negative
+// index wraps (tracking.py:219), never reach this function (sitrk_run steps such buoy sets record by record).
+//   row kc-1:  [0] va  [1] vb  [2] eA  [3] eB   byte offsets into `geo` relative to the host cell's record
+//              [4] S   [5] A   [6] B            packed-cell increments (dj << 16) + di   straight / first / second diagonal
+//              [7] S   [8] A   [9] B            cell-index increments dj*Ni + di
+//              [10] S  [11] A  [12] B           bit of the 3x3 Survive word (dj+1)*3 + (di+1)
+// ---------------------------------------------------------------------------
+struct CrossTab { int v[4][16]; };
+
+__host__ inline void make_cross_tab(int Ni, CrossTab &t)
+{
+    // kc: 1 bottom, 2 right, 3 upper, 4 left.  (dj,di) of va, vb (the crossed edge's ends as F-points relative to F[jT,iT]),
+    // of the two extension points, and of the straight / A / B destination cells -- the table of resolve_crossing above
+    static const int va[4][2] = {{-1, -1}, {-1, 0}, {0, -1}, {0, -1}}, vb[4][2] = {{-1, 0}, {0, 0}, {0, 0}, {-1, -1}};
+    static const int eA[4][2] = {{-2, -1}, {-1, 1}, {1, -1}, {0, -2}}, eB[4][2] = {{-2, 0}, {0, 1}, {1, 0}, {-1, -2}};
+    static const int dS[4][2] = {{-1, 0}, {0, 1}, {1, 0}, {0, -1}}, dA[4][2] = {{-1, -1}, {-1, 1}, {1, -1}, {1, -1}},
+                     dB[4][2] = {{-1, 1}, {1, 1}, {1, 1}, {-1, -1}};
+    for (int e = 0; e < 4; e++) {
+        int *r = t.v[e];
+        for (int q = 0; q < 16; q++) r[q] = 0;
+        r[0] = (va[e][0] * Ni + va[e][1]) * (int)sizeof(CellGeo);
+        r[1] = (vb[e][0] * Ni + vb[e][1]) * (int)sizeof(CellGeo);
+        r[2] = (eA[e][0] * Ni + eA[e][1]) * (int)sizeof(CellGeo);
+        r[3] = (eB[e][0] * Ni + eB[e][1]) * (int)sizeof(CellGeo);
+        const int(*d[3])[2] = {dS, dA, dB};
+        for (int q = 0; q < 3; q++) {
+            const int dj = d[q][e][0], di = d[q][e][1];
+            r[4 + q] = dj * 65536 + di;
+            r[7 + q] = dj * Ni + di;
+            r[10 + q] = (dj + 1) * 3 + (di + 1);
+        }
+    }
+}
+
+// a point of the geometry at (scalar base + 32-bit byte offset + immediate): no 64-bit address arithmetic per lane
+__device__ __forceinline__ pt geo_pt(const char *__restrict__ gb, unsigned off, int imm = 0)
+{
+    return *(const pt *)(gb + (size_t)off + (ptrdiff_t)imm);
+}
+
+// P1 -> P2 leaves the cell whose quad is (bl, br, ur, ul); k48 = byte offset of the cell's geometry record, kcell = its
+// index.  Returns the crossed edge kc (1..4) and fills the increments of the destination cell; `killed` = its Survive byte.
+// Same predicates on the same operands in the same order as resolve_crossing().
+__device__ __forceinline__ int resolve_crossing_tab(pt P1, pt P2, pt bl, pt br, pt ur, pt ul, unsigned k48, unsigned kcell,
+                                                    const char *__restrict__ gb, const uint16_t *__restrict__ kill9,
+                                                    const int *__restrict__ tab /* LDS */, int &dcell, int &dk, bool &killed,
+                                                    int *codes = nullptr)
+{
+    const bool sbl = ccw(P1, P2, bl), sbr = ccw(P1, P2, br), sur = ccw(P1, P2, ur), sul = ccw(P1, P2, ul);
+    const bool h1 = (ccw(P1, bl, br) != ccw(P2, bl, br)) && (sbl != sbr);
+    const bool h2 = (ccw(P1, br, ur) != ccw(P2, br, ur)) && (sbr != sur);
+    const bool h3 = (ccw(P1, ur, ul) != ccw(P2, ur, ul)) && (sur != sul);
+    const int kc = h1 ? 1 : (h2 ? 2 : (h3 ? 3 : 4));
+    const int *row = tab + 16 * (kc - 1);
+    const int4 r0 = *(const int4 *)(row), r1 = *(const int4 *)(row + 4), r2 = *(const int4 *)(row + 8);
+    const int bB = row[12];
+    // one batch of independent loads: the crossed edge's two ends, the two extension points, the 3x3 Survive word
+    const pt va = geo_pt(gb, k48 + (unsigned)r0.x), vb = geo_pt(gb, k48 + (unsigned)r0.y);
+    const pt eA = geo_pt(gb, k48 + (unsigned)r0.z), eB = geo_pt(gb, k48 + (unsigned)r0.w);
+    const unsigned k9 = kill9[kcell];
+    // NewHostCell (:217-243): first the side test of the two ends of the move against each prolongation ...
+    bool hitA = ccw(P1, va, eA) != ccw(P2, va, eA);
+    bool hitB = ccw(P1, vb, eB) != ccw(P2, vb, eB);
+    // ... and only for lanes that pass it the second half of intersect2Seg (a diagonal move is rare: most waves skip this)
+    if (hitA || hitB) {
+        hitA = hitA && (ccw(P1, P2, va) != ccw(P1, P2, eA));
+        hitB = hitB && (ccw(P1, P2, vb) != ccw(P1, P2, eB));
+    }
+    // UpdtInd4NewCell (:257-300); first match wins (if / elif)
+    dcell = hitA ? r1.y : (hitB ? r1.z : r1.x);
+    dk = hitA ? r2.x : (hitB ? r2.y : r1.w);
+    const int bit = hitA ? r2.w : (hitB ? bB : r2.z);
+    killed = ((k9 >> bit) & 1u) != 0;                                        // Survive (:483-484)
+    if (codes) {
+        const int cA = (kc == 1) ? 5 : (kc == 2) ? 6 : 8, cB = (kc == 1) ? 6 : (kc == 4) ? 5 : 7;
+        codes[0] = kc;
+        codes[1] = hitA ? cA : (hitB ? cB : kc);
+    }
+    return kc;
+}
 
 typedef double v2d __attribute__((ext_vector_type(2)));
 
@@ -337,7 +451,8 @@ struct RunArgs {
     StepArgs s;                         // s.u/s.v/s.kill unused; s.jrec = first record
     int nrec;
     const void *u[kMaxFuse], *v[kMaxFuse];
-    const int8_t *kill[kMaxFuse];
+    const uint16_t *kill9[kMaxFuse];    // 3x3 Survive words of each record (pack_kill9_kernel)
+    CrossTab tab;                       // crossing table (make_cross_tab), copied to LDS by every workgroup
 };
 
 // ---------------------------------------------------------------------------
@@ -357,18 +472,18 @@ struct CellCtx {
     bool sFV, sFU;                      // ccw(F11,V01,V11), ccw(F11,U10,U11)
 };
 
+// all eight points from two 32-bit byte offsets (the cell's record and the one a row below) + immediates
 template <unsigned ES>
-__device__ __forceinline__ void load_ctx(const StepArgs &a, int32_t c, CellCtx &x)
+__device__ __forceinline__ void load_ctx(const StepArgs &a, const char *__restrict__ gb, unsigned kcell, CellCtx &x)
 {
-    const int Ni = a.Ni;
-    const unsigned k = (unsigned)(cell_j(c) * Ni + cell_i(c));
-    x.o1 = k * ES; x.o0 = (k - (unsigned)Ni) * ES;
-    const CellGeo g11 = a.geo[k];
-    x.F11 = g11.f; x.U11 = g11.u; x.V11 = g11.v;
-    x.F10 = a.geo[k - 1].f; x.U10 = a.geo[k - 1].u;
-    x.F01 = a.geo[k - Ni].f; x.V01 = a.geo[k - Ni].v;
-    x.F00 = a.geo[k - Ni - 1].f;
-    const int8_t ori = a.orient[k];
+    const unsigned Ni = (unsigned)a.Ni;
+    x.o1 = kcell * ES; x.o0 = (kcell - Ni) * ES;
+    const unsigned k48 = kcell * (unsigned)sizeof(CellGeo), k48b = k48 - Ni * (unsigned)sizeof(CellGeo);
+    x.F11 = geo_pt(gb, k48, 0); x.U11 = geo_pt(gb, k48, 16); x.V11 = geo_pt(gb, k48, 32);
+    x.F10 = geo_pt(gb, k48, -48); x.U10 = geo_pt(gb, k48, -32);
+    x.F01 = geo_pt(gb, k48b, 0); x.V01 = geo_pt(gb, k48b, 32);
+    x.F00 = geo_pt(gb, k48b, -48);
+    const int8_t ori = a.orient[kcell];
     x.sFV = (ori & 1) != 0;             // ccw(F11, V01, V11)
     x.sFU = (ori & 2) != 0;             // ccw(F11, U10, U11)
 }
@@ -376,6 +491,9 @@ __device__ __forceinline__ void load_ctx(const StepArgs &a, int32_t c, CellCtx &
 template <typename FT, int UVS, bool WINDOW>
 __global__ __launch_bounds__(kBlock, 5) void advect_run_kernel(RunArgs ra)
 {
+    __shared__ __attribute__((aligned(16))) int s_tab[64];
+    if (threadIdx.x < 64) s_tab[threadIdx.x] = ((const int *)&ra.tab)[threadIdx.x];
+    __syncthreads();                                     // the only barrier: before any lane can leave
     const StepArgs &a = ra.s;
     const unsigned blk = (a.tune & TUNE_XCD_REMAP) ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
     const int64_t p = (int64_t)blk * kBlock + threadIdx.x;
@@ -387,10 +505,10 @@ __global__ __launch_bounds__(kBlock, 5) void advect_run_kernel(RunArgs ra)
     if (WINDOW) { first = a.first[p]; last = a.last[p]; }
     pt P = nt ? load_pt_nt(&a.pos[p]) : a.pos[p];
     const int32_t c0 = c;
-    const int Ni = a.Ni, Nj = a.Nj;
+    const char *__restrict__ gb = (const char *)a.geo;
     bool moved = false;
     CellCtx x;
-    load_ctx<sizeof(FT)>(a, c, x);
+    load_ctx<sizeof(FT)>(a, gb, (unsigned)(cell_j(c) * a.Ni + cell_i(c)), x);
     // the record pointers (scalar loads from the kernel arguments) are fetched one record ahead: a record's vector
     // loads go out at the top of its iteration instead of behind a scalar load and its wait (-0.7 %)
     const char *ub_next = (const char *)ra.u[0], *vb_next = (const char *)ra.v[0];
@@ -431,11 +549,16 @@ __global__ __launch_bounds__(kBlock, 5) void advect_run_kernel(RunArgs ra)
         moved = true;
         bool killed = false;
         if (!SITRK_INSIDE(Pn.y, Pn.x, x.F00, x.F01, x.F11, x.F10, a.eps_mg)) {      // :466-484
-            c = resolve_crossing(P, Pn, x.F00, x.F01, x.F11, x.F10, cell_j(c), cell_i(c), Nj, Ni, a.geo, ra.kill[r], killed);
-            if (!killed) load_ctx<sizeof(FT)>(a, c, x);
+            const unsigned kcell = x.o1 / (unsigned)sizeof(FT);
+            int dcell, dk;
+            resolve_crossing_tab(P, Pn, x.F00, x.F01, x.F11, x.F10, kcell * (unsigned)sizeof(CellGeo), kcell, gb, ra.kill9[r], s_tab,
+                                 dcell, dk, killed);
+            c += dcell;
+            if (!killed) load_ctx<sizeof(FT)>(a, gb, kcell + (unsigned)dk, x);
         }
         P = Pn;
         if (killed) {
+            c |= SITRK_DEAD_BIT;
             a.kill_rec[p] = jrec;
             break;                                       // dead buoys never step again
         }
@@ -539,16 +662,31 @@ __global__ void eval_intersect_kernel(int64_t n, const pt *__restrict__ segs, in
 
 __global__ void eval_crossing_kernel(int64_t n, int Nj, int Ni, const CellGeo *__restrict__ geo, const int8_t *__restrict__ zero_mask,
                                      const pt *__restrict__ P1, const pt *__restrict__ P2, const int32_t *__restrict__ jiT,
-                                     int32_t *__restrict__ jiT_new, int32_t *__restrict__ codes_out)
+                                     int32_t *__restrict__ jiT_new, int32_t *__restrict__ codes_out, CrossTab tab)
 {
+    __shared__ __attribute__((aligned(16))) int s_tab[64];
+    if (threadIdx.x < 64) s_tab[threadIdx.x] = ((const int *)&tab)[threadIdx.x];
+    __syncthreads();
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const int jT = jiT[2 * p], iT = jiT[2 * p + 1];
     const size_t k = (size_t)jT * Ni + iT;
     bool killed;
     int codes[2];
-    const int32_t cn = resolve_crossing(P1[p], P2[p], geo[k - Ni - 1].f, geo[k - Ni].f, geo[k].f, geo[k - 1].f, jT, iT, Nj, Ni, geo,
-                                        zero_mask, killed, codes);
+    const pt bl = geo[k - Ni - 1].f, br = geo[k - Ni].f, ur = geo[k].f, ul = geo[k - 1].f;
+    int32_t cn = resolve_crossing(P1[p], P2[p], bl, br, ur, ul, jT, iT, Nj, Ni, geo, zero_mask, killed, codes);
+    // the table-driven form of the fused kernel (cells it is used for: no negative-index wrap; 32-bit byte offsets)
+    if (jT >= 2 && iT >= 2 && (size_t)Nj * Ni * sizeof(CellGeo) < ((size_t)1 << 32)) {
+        int dcell, dk, codes2[2];
+        bool killed2;
+        // (zero_mask is all zeros: read as 16-bit words it is a valid "nothing kills" 3x3 word array of half the length)
+        resolve_crossing_tab(P1[p], P2[p], bl, br, ur, ul, (unsigned)k * (unsigned)sizeof(CellGeo), (unsigned)k / 2u, (const char *)geo,
+                             (const uint16_t *)zero_mask, s_tab, dcell, dk, killed2, codes2);
+        const int32_t cn2 = pack_cell(jT, iT) + dcell;
+        const bool same = (cn2 == cn) && (codes2[0] == codes[0]) && (codes2[1] == codes[1]) && !killed2 &&
+                          ((int64_t)k + dk == (int64_t)cell_j(cn) * Ni + cell_i(cn));
+        if (!same) { cn = pack_cell(0, 0); codes[0] = codes[1] = -1; }      // the two forms disagree: make the tests fail loudly
+    }
     jiT_new[2 * p] = cell_j(cn);
     jiT_new[2 * p + 1] = cell_i(cn);
     if (codes_out) {
