@@ -75,6 +75,10 @@ def parse():
     ap.add_argument("--e2e-full", action="store_true", help="e2e regime: upload whole records instead of the row band the buoys can touch")
     ap.add_argument("--e2e-library", action="store_true",
                     help="e2e regime through the library's own pinned staging and copy stream (sitrk_stage_*), host fill included")
+    ap.add_argument("--only-fused", action="store_true",
+                    help="skip the two reference legs (one record per launch, 8 records per launch): profiling runs, so that every "
+                         "dispatch of advect_run_kernel in the trace is a launch of the timed configuration")
+    ap.add_argument("--tune", default="", help="library tuning knobs for A/B runs, e.g. patch_kb=0,sort_tile=2080 (never change results)")
     ap.add_argument("--no-c2", action="store_true", help="skip the C2 (512x512, 1e5 buoys, 1000 steps) sub-measurement")
     ap.add_argument("--no-e2e-broadcast", action="store_true",
                     help="N > 1: skip the short end-to-end segment (one RCCL broadcast per record, overlapped with stepping)")
@@ -282,6 +286,8 @@ def main():
     ctx.set_grid(grid["Yf"], grid["Xf"], grid["Yu"], grid["Xu"], grid["Yv"], grid["Xv"], grid["tmask"])
     ctx.set_params(3600., a.uv_strategy, 0.1)
     ctx.alloc_records(K, np.float32)
+    if a.tune:
+        ctx.set_tuning(**{kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.tune.split(",")})
 
     # host cells through the product's own FindContainingCell (also validates the analytic guess)
     found, ji2 = ctx.find_cells(yx, ji)
@@ -349,12 +355,12 @@ def main():
         ctx.run(0, 0, a.warmup)
         dt, ev_ms, stats = timed_run(a.warmup, a.steps, fuse)
         nrun = a.warmup + a.steps
-        if fuse > 1:
+        if fuse > 1 and not a.only_fused:
             # for reference: the same K steps with one launch per record (the HBM-bound form of the kernel)
             dt1, ev1_ms, st1 = timed_run(nrun, a.steps, 1)
             per_record = (dt1, ev1_ms, st1)
             nrun += a.steps
-        if fuse > 8:
+        if fuse > 8 and not a.only_fused:
             # for reference: 8 records per launch (the K = 8 of SURVEY 8d's synthetic set-up allows no more)
             eight = timed_run(nrun, a.steps, 8)[0]
             nrun += a.steps
@@ -557,7 +563,8 @@ def main():
                        "sorted": not a.no_sort, "resort_every": 0 if a.no_sort else resort, "regime": a.regime,
                        "records_per_launch": fuse,
                        "e2e_upload_bytes_per_step": (e2e_bytes_per_step if a.regime == "e2e" else None),
-                       "partition": "buoy-range x%d" % world, "records_via": records_via, "alive_after": nalive},
+                       "partition": "buoy-range x%d" % world, "records_via": records_via, "alive_after": nalive,
+                       "tune": a.tune or None},
             "roofline": roof,
         }
         if per_record is not None:

@@ -89,6 +89,8 @@ int sitrk_set_params(sitrk_t *h, double rdt, int uv_strategy, double rmin_conc);
  * the once-per-step position/cell streams; "sort_tile" (tile_j*256 + tile_i, 0 = row-major):
  * order of the cell sort, tile-major tiles of tile_j x tile_i cells; "locate_bruteforce" (0/1):
  * SeedInit scans the whole grid per seed like the reference instead of the bounding-sphere search;
+ * "patch_kb" (0..63, default 40) / "patch_margin": LDS bytes per workgroup that the fused kernel may fill with the geometry of
+ * the cells around its buoys (0 = none: every geometry read goes to global memory), and the widest margin of cells it takes;
  * "step_block" (256/512/1024): workgroup size of the one-record kernel; "fuse" (1..32): consecutive resident records advanced per launch by sitrk_run (loop interchange: the
  * buoys are independent, each lane keeps its buoy in registers across the records). */
 int sitrk_set_tuning(sitrk_t *h, const char *knob, int value);

@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libsitrk.so")
+# the in-tree build; SITRK_LIB_PATH points A/B tooling (tools/build_variant.sh) at another build of the same sources
+SO_PATH = os.environ.get("SITRK_LIB_PATH") or os.path.join(_HERE, "libsitrk.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 SITRK_F32, SITRK_F64 = 0, 1

@@ -129,7 +129,7 @@ SITRK_API int sitrk_destroy(sitrk_t *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_buoys(h);
     free_records(h);
-    dev_free(h->geo); dev_free(h->orient); dev_free(h->tmask); dev_free(h->scratch); dev_free(h->counter);
+    dev_free(h->geo); dev_free(h->geoF); dev_free(h->orient); dev_free(h->tmask); dev_free(h->scratch); dev_free(h->counter);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     for (int b = 0; b < sitrk_ctx::kStage; b++) if (h->stage_done[b]) (void)hipEventDestroy(h->stage_done[b]);
@@ -170,12 +170,13 @@ SITRK_API int sitrk_set_grid(sitrk_t *h, int Nj, int Ni, const double *Yf, const
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->copy_stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    dev_free(h->geo); dev_free(h->orient); dev_free(h->tmask);
-    h->geo = nullptr; h->orient = nullptr; h->tmask = nullptr;
+    dev_free(h->geo); dev_free(h->geoF); dev_free(h->orient); dev_free(h->tmask);
+    h->geo = nullptr; h->geoF = nullptr; h->orient = nullptr; h->tmask = nullptr;
     free_records(h);
     free_buoys(h);
     const size_t n = (size_t)Nj * Ni;
     HIPCHK(dev_alloc(&h->geo, n));
+    HIPCHK(dev_alloc(&h->geoF, n));
     HIPCHK(dev_alloc(&h->orient, n));
     HIPCHK(dev_alloc(&h->tmask, n));
     // stage the six arrays in scratch, interleave on the device
@@ -186,7 +187,7 @@ SITRK_API int sitrk_set_grid(sitrk_t *h, int Nj, int Ni, const double *Yf, const
     for (int a = 0; a < 6; a++) HIPCHK(hipMemcpyAsync(s + a * n, src[a], n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->tmask, tmask, n, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(build_geo_kernel, dim3(nblocks((int64_t)n)), dim3(kBlock), 0, h->stream, n, s, s + n, s + 2 * n, s + 3 * n,
-                       s + 4 * n, s + 5 * n, h->geo);
+                       s + 4 * n, s + 5 * n, h->geo, h->geoF);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(cell_orient_kernel, dim3(nblocks((int64_t)n)), dim3(kBlock), 0, h->stream, Nj, Ni, h->geo, h->orient);
     HIPCHK(hipGetLastError());
@@ -222,6 +223,8 @@ SITRK_API int sitrk_set_tuning(sitrk_t *h, const char *knob, int value)
     int bit = 0;
     if (!strcmp(knob, "xcd_remap")) bit = TUNE_XCD_REMAP;
     else if (!strcmp(knob, "nt_state")) bit = TUNE_NT_STATE;
+    else if (!strcmp(knob, "prefetch")) bit = TUNE_PREFETCH;
+    else if (!strcmp(knob, "prefetch_v0")) bit = TUNE_PREFETCH_V0;
     else if (!strcmp(knob, "step_block")) {          // workgroup size of advect_step_kernel
         if (value != 256 && value != 512 && value != 1024) return fail(h, SITRK_EINVAL, "sitrk_set_tuning: step_block must be 256, 512 or 1024");
         h->step_block = value;
@@ -236,6 +239,16 @@ SITRK_API int sitrk_set_tuning(sitrk_t *h, const char *knob, int value)
         const int tj = value >> 8, ti = value & 255;
         if (value != 0 && (tj < 1 || ti < 1)) return fail(h, SITRK_EINVAL, "sitrk_set_tuning: sort_tile = tile_j*256 + tile_i");
         h->tile_j = tj; h->tile_i = ti;
+        return SITRK_OK;
+    }
+    else if (!strcmp(knob, "patch_kb")) {            // LDS bytes (KiB) per workgroup for the fused kernel's geometry patch
+        if (value < 0 || value > 63) return fail(h, SITRK_EINVAL, "sitrk_set_tuning: patch_kb must be 0..63");
+        h->patch_kb = value;
+        return SITRK_OK;
+    }
+    else if (!strcmp(knob, "patch_margin")) {
+        if (value < 0 || value > 64) return fail(h, SITRK_EINVAL, "sitrk_set_tuning: patch_margin must be 0..64");
+        h->patch_margin = value;
         return SITRK_OK;
     }
     else if (!strcmp(knob, "locate_bruteforce")) bit = TUNE_LOCATE_BRUTEFORCE;
@@ -253,8 +266,8 @@ static inline size_t elem_size(int dtype) { return dtype == SITRK_F64 ? 8 : 4; }
 
 static void free_records(sitrk_ctx *h)
 {
-    dev_free(h->slabs); dev_free(h->kill);
-    h->slabs = nullptr; h->kill = nullptr; h->nslots = 0;
+    dev_free(h->slabs); dev_free(h->kill); dev_free(h->kill9);
+    h->slabs = nullptr; h->kill = nullptr; h->kill9 = nullptr; h->nslots = 0;
     for (int b = 0; b < sitrk_ctx::kStage; b++) {
         if (h->stage[b]) (void)hipHostFree(h->stage[b]);
         h->stage[b] = nullptr;
@@ -279,9 +292,11 @@ SITRK_API int sitrk_alloc_records(sitrk_t *h, int nslots, int dtype)
     h->slab_bytes = 3 * n * elem_size(dtype);
     HIPCHK(hipMalloc(&h->slabs, h->slab_bytes * nslots));
     HIPCHK(hipMalloc((void **)&h->kill, n * nslots));
+    HIPCHK(hipMalloc((void **)&h->kill9, n * nslots * sizeof(uint8_t)));
     // sentinels: a read outside the rows that were uploaded must be detectable, not silent garbage --
     // every Survive byte starts as "kill", every field value as NaN (0xff.. is a NaN in fp32 and fp64)
     HIPCHK(hipMemsetAsync(h->kill, 1, n * nslots, h->stream));
+    HIPCHK(hipMemsetAsync(h->kill9, 0xff, n * nslots * sizeof(uint8_t), h->stream));
     HIPCHK(hipMemsetAsync(h->slabs, 0xff, h->slab_bytes * nslots, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->nslots = nslots; h->dtype = dtype;
@@ -342,6 +357,10 @@ static int derive_mask_rows(sitrk_ctx *h, int slot, int j0, int j1, int v0, int 
             hipLaunchKernelGGL((survive_mask_rows_kernel<float>), dim3(nblocks(cells)), dim3(kBlock), 0, h->stream, h->Nj, h->Ni, j0, j1, v0, v1,
                                h->tmask, (const float *)sic, h->rmin_conc, kill);
     }
+    HIPCHK(hipGetLastError());
+    // the 3x3 neighbourhoods of those bytes, one word per cell, for the fused kernel
+    hipLaunchKernelGGL(pack_kill9_kernel, dim3(nblocks((int64_t)(j1 - j0) * h->Ni)), dim3(kBlock), 0, h->stream, h->Nj, h->Ni, j0, j1, v0, v1,
+                       kill, h->kill9 + (size_t)slot * n);
     HIPCHK(hipGetLastError());
     h->slot_dirty[slot] = 0;
     return SITRK_OK;
@@ -530,13 +549,16 @@ SITRK_API int sitrk_set_buoys(sitrk_t *h, int64_t nP, const double *yx, const in
     } catch (const std::bad_alloc &) {          // no C++ exception may cross the C ABI
         return fail(h, SITRK_ENOMEM, "sitrk_set_buoys: out of host memory for %lld buoys", (long long)nP);
     }
+    bool rim = false;
     for (int64_t p = 0; p < nP; p++) {
         int j = jiT[2 * p], i = jiT[2 * p + 1];
         if (j < 1 || j > h->Nj - 2 || i < 1 || i > h->Ni - 2)
             return fail(h, SITRK_EINDEX, "sitrk_set_buoys: buoy %lld host cell (%d,%d) outside 1..%d x 1..%d "
                         "(the reference would index out of range)", (long long)p, j, i, h->Nj - 2, h->Ni - 2);
         packed[(size_t)p] = pack_cell(j, i);
+        rim = rim || j < 2 || i < 2;
     }
+    h->rim_buoys = rim;
     for (int b = 0; b < 2; b++) {
         HIPCHK(dev_alloc(&h->st[b].pos, (size_t)nP));
         HIPCHK(dev_alloc(&h->st[b].cell, (size_t)nP));
@@ -684,17 +706,19 @@ template <typename FT>
 static void launch_run(sitrk_ctx *h, const RunArgs &ra)
 {
     dim3 grid(nblocks(ra.s.nP)), block(kBlock);
+    // dynamic LDS: tables + the patch's F-points
+    const size_t lds = kRunLdsFixed + (size_t)ra.patch_cells * sizeof(pt);
 #define SITRK_LAUNCH_RUN(KERNEL)                                                                          \
     do {                                                                                                  \
         if (h->uv_strategy == 1) {                                                                        \
-            if (h->windowed) hipLaunchKernelGGL((KERNEL<FT, 1, true>), grid, block, 0, h->stream, ra);    \
-            else hipLaunchKernelGGL((KERNEL<FT, 1, false>), grid, block, 0, h->stream, ra);               \
+            if (h->windowed) hipLaunchKernelGGL((KERNEL<FT, 1, true>), grid, block, lds, h->stream, ra);  \
+            else hipLaunchKernelGGL((KERNEL<FT, 1, false>), grid, block, lds, h->stream, ra);             \
         } else if (h->uv_strategy == 2) {                                                                 \
-            if (h->windowed) hipLaunchKernelGGL((KERNEL<FT, 2, true>), grid, block, 0, h->stream, ra);    \
-            else hipLaunchKernelGGL((KERNEL<FT, 2, false>), grid, block, 0, h->stream, ra);               \
+            if (h->windowed) hipLaunchKernelGGL((KERNEL<FT, 2, true>), grid, block, lds, h->stream, ra);  \
+            else hipLaunchKernelGGL((KERNEL<FT, 2, false>), grid, block, lds, h->stream, ra);             \
         } else {                                                                                          \
-            if (h->windowed) hipLaunchKernelGGL((KERNEL<FT, 0, true>), grid, block, 0, h->stream, ra);    \
-            else hipLaunchKernelGGL((KERNEL<FT, 0, false>), grid, block, 0, h->stream, ra);               \
+            if (h->windowed) hipLaunchKernelGGL((KERNEL<FT, 0, true>), grid, block, lds, h->stream, ra);  \
+            else hipLaunchKernelGGL((KERNEL<FT, 0, false>), grid, block, lds, h->stream, ra);             \
         }                                                                                                 \
     } while (0)
     SITRK_LAUNCH_RUN(advect_run_kernel);
@@ -709,7 +733,11 @@ SITRK_API int sitrk_run(sitrk_t *h, int slot0, int jrec0, int nsteps)
     NEED(slot0 >= 0 && slot0 < h->nslots, "sitrk_run: slot0 out of range");
     NEED(h->st[0].pos, "sitrk_run: call sitrk_set_buoys first");
     if (h->nP == 0) return SITRK_OK;
-    const int fuse = std::max(1, std::min(std::min(h->fuse, kMaxFuse), h->nslots));    // a launch never wraps the slot ring
+    int fuse = std::max(1, std::min(std::min(h->fuse, kMaxFuse), h->nslots));    // a launch never wraps the slot ring
+    // the fused kernel addresses the geometry with 32-bit byte offsets and has no negative-index wrap: buoy sets seeded in
+    // the two outermost rows/columns (the reference itself cancels such seeds, tracking.py:73) and meshes beyond
+    // 2^32 / 48 cells (9 460 x 9 460) are stepped record by record
+    if (h->rim_buoys || (uint64_t)h->Nj * h->Ni * sizeof(CellGeo) >= ((uint64_t)1 << 32)) fuse = 1;
     const size_t n = (size_t)h->Nj * h->Ni, es = elem_size(h->dtype);
     int k = 0;
     while (k < nsteps) {
@@ -732,6 +760,10 @@ SITRK_API int sitrk_run(sitrk_t *h, int slot0, int jrec0, int nsteps)
         ra.s.rdt = h->rdt; ra.s.rmin_conc = h->rmin_conc; ra.s.eps_mg = h->eps_mg; ra.s.geo = h->geo; ra.s.orient = h->orient; ra.s.kill = nullptr; ra.s.u = ra.s.v = nullptr;
         ra.s.pos = s.pos; ra.s.cell = s.cell; ra.s.kill_rec = s.kill_rec; ra.s.first = s.first; ra.s.last = s.last;
         ra.nrec = m;
+        make_cross_tab(h->Ni, ra.tab, ra.dji);
+        ra.geoF = h->geoF;
+        ra.patch_cells = (int)((size_t)h->patch_kb * 1024 / sizeof(pt));
+        ra.patch_margin = h->patch_margin;
         int used[kMaxFuse];
         for (int r = 0; r < m; r++) {
             const int slot = (slot0 + k + r) % h->nslots;
@@ -745,7 +777,7 @@ SITRK_API int sitrk_run(sitrk_t *h, int slot0, int jrec0, int nsteps)
             rc = slot_wait_upload(h, slot);
             if (rc) return rc;
             const char *slab = slab_of(h, slot);
-            ra.u[r] = slab; ra.v[r] = slab + n * es; ra.kill[r] = h->kill + (size_t)slot * n;
+            ra.u[r] = slab; ra.v[r] = slab + n * es; ra.kill9[r] = h->kill9 + (size_t)slot * n;
         }
         if (h->dtype == SITRK_F64) launch_run<double>(h, ra);
         else launch_run<float>(h, ra);
@@ -1147,8 +1179,10 @@ SITRK_API int sitrk_eval_crossing(sitrk_t *h, int64_t n, const double *P1, const
     HIPCHK(hipMemcpyAsync(d2, P2, (size_t)n * sizeof(pt), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(dj, jiT, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemsetAsync(zero, 0, cells, h->stream));
+    CrossTab tab;
+    make_cross_tab(h->Ni, tab);
     hipLaunchKernelGGL(eval_crossing_kernel, dim3(nblocks(n)), dim3(kBlock), 0, h->stream, n, h->Nj, h->Ni, h->geo, zero, d1, d2, dj, dn,
-                       codes ? dc : nullptr);
+                       codes ? dc : nullptr, tab);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(jiT_new, dn, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
     if (codes) HIPCHK(hipMemcpyAsync(codes, dc, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));

@@ -46,6 +46,7 @@ struct sitrk_ctx {
     // grid
     int Nj = 0, Ni = 0;
     sitrk::CellGeo *geo = nullptr;      // (Nj*Ni) 48-byte records
+    sitrk::pt *geoF = nullptr;          // (Nj*Ni) F-points alone: the fused kernel fills its LDS patches from contiguous rows of it
     int8_t *orient = nullptr;           // (Nj*Ni) orientation bits of the velocity pick (cell_orient_kernel)
     int8_t *tmask = nullptr;
 
@@ -60,12 +61,15 @@ struct sitrk_ctx {
     int step_block = 512;               // workgroup size of advect_step_kernel (512: -3.6 % vs 256, 1024: +1.8 %)
     int fuse = 32;                      // sitrk_run: consecutive resident records advanced per launch, <= nslots (1 = one launch per record)
     int tile_j = 8, tile_i = 16;        // sort order: 0 = row-major cells, else tile-major tiles of tile_j x tile_i cells
+    int patch_kb = 16;                  // fused kernel: LDS bytes per workgroup for its geometry patch (0 = none, all reads global)
+    int patch_margin = 8;               // ... and the widest margin of cells around the buoys' bounding box it may take
 
     // records
     int nslots = 0, dtype = 0;
     size_t slab_bytes = 0;
     void *slabs = nullptr;              // nslots * [u|v|sic]
     int8_t *kill = nullptr;             // nslots * (Nj*Ni) Survive masks derived from (tmask, sic, rmin_conc)
+    uint8_t *kill9 = nullptr;           // nslots * (Nj*Ni) 3x3 neighbourhoods of those bytes, one word per cell (fused kernel)
     unsigned char slot_dirty[4096] = {0};   // slab (re)written since its mask was derived
     // per slot: upload still in flight on copy_stream (the compute stream waits for slot_ready before it reads the
     // slot; events are created on first use), and the sequence number of the last launch that reads the slot (an upload
@@ -88,6 +92,7 @@ struct sitrk_ctx {
     // buoys
     int64_t nP = 0;
     bool windowed = false;
+    bool rim_buoys = false;             // some buoy was set in a cell with jT < 2 or iT < 2 (numpy negative-index wrap possible)
     sitrk::BuoyState st[2];             // double buffer for the sort
     int cur = 0;
     uint32_t *keys[2] = {nullptr, nullptr};

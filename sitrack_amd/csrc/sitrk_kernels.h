@@ -23,12 +23,13 @@ static constexpr int kBlock = 256;
 __global__ void build_geo_kernel(size_t n, const double *__restrict__ Yf, const double *__restrict__ Xf,
                                  const double *__restrict__ Yu, const double *__restrict__ Xu,
                                  const double *__restrict__ Yv, const double *__restrict__ Xv,
-                                 CellGeo *__restrict__ geo)
+                                 CellGeo *__restrict__ geo, pt *__restrict__ geoF)
 {
     size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     CellGeo g;
     g.f = make_pt(Yf[k], Xf[k]);
+    geoF[k] = g.f;
     g.u = make_pt(Yu[k], Xu[k]);
     g.v = make_pt(Yv[k], Xv[k]);
     geo[k] = g;
@@ -99,17 +100,20 @@ __global__ void survive_mask_rows_kernel(int Nj, int Ni, int j_lo, int j_hi, int
     kill[(size_t)j * Ni + i] = survive_kill<FT>(j, i, Nj, Ni, tmask, sic, rmin_conc) ? 1 : 0;
 }
 
-// The fused kernel reads ONE 16-bit word per crossing instead of three Survive bytes at computed addresses: bit
-// (dj+1)*3 + (di+1) of kill9[j,i] = Survive byte of cell (j+dj, i+di).  Packed from the byte mask for rows [j_lo, j_hi);
+// The fused kernel reads ONE byte per buoy and record instead of three Survive bytes at computed addresses per crossing:
+// the Survive bytes of the 8 neighbours of cell (j,i), bit b of kill9[j,i] = cell (j+dj, i+di) with (dj+1)*3 + (di+1) = b
+// for b < 4 and b + 1 otherwise (the centre is never a destination).  It is requested together with the record's velocities,
+// at the top of a record's iteration, not behind the crossing test: it is the one crossing-path operand that is new with
+// every record, i.e. never in cache.  Packed from the byte mask for rows [j_lo, j_hi);
 // a row whose three byte rows are not all valid (valid = domain rim, or inside (v_lo, v_hi-1): see
 // survive_mask_rows_kernel) gets the sentinel "everything kills".
 __global__ void pack_kill9_kernel(int Nj, int Ni, int j_lo, int j_hi, int v_lo, int v_hi, const int8_t *__restrict__ kill,
-                                  uint16_t *__restrict__ kill9)
+                                  uint8_t *__restrict__ kill9)
 {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)(j_hi - j_lo) * Ni) return;
     const int j = j_lo + (int)(t / (size_t)Ni), i = (int)(t % (size_t)Ni);
-    unsigned w = 0x1ffu;
+    unsigned w = 0xffu;
     bool ok = (j >= 1 && j <= Nj - 2 && i >= 1 && i <= Ni - 2);
     for (int dj = -1; dj <= 1 && ok; dj++) {
         const int r = j + dj;
@@ -122,10 +126,12 @@ __global__ void pack_kill9_kernel(int Nj, int Ni, int j_lo, int j_hi, int v_lo, 
 #pragma unroll
         for (int dj = -1; dj <= 1; dj++)
 #pragma unroll
-            for (int di = -1; di <= 1; di++)
-                w |= (kill[k + (ptrdiff_t)dj * Ni + di] ? 1u : 0u) << ((dj + 1) * 3 + (di + 1));
+            for (int di = -1; di <= 1; di++) {
+                const int b9 = (dj + 1) * 3 + (di + 1);
+                if (b9 != 4) w |= (kill[k + (ptrdiff_t)dj * Ni + di] ? 1u : 0u) << (b9 < 4 ? b9 : b9 - 1);
+            }
     }
-    kill9[(size_t)j * Ni + i] = (uint16_t)w;
+    kill9[(size_t)j * Ni + i] = (uint8_t)w;
 }
 
 // rows of the host cells of the buoys that are still alive: out[0] = min jT, out[1] = max jT
@@ -226,11 +232,11 @@ __device__ __forceinline__ int32_t resolve_crossing(pt P1, pt P2, pt bl, pt br, 
 //   row kc-1:  [0] va  [1] vb  [2] eA  [3] eB   byte offsets into `geo` relative to the host cell's record
 //              [4] S   [5] A   [6] B            packed-cell increments (dj << 16) + di   straight / first / second diagonal
 //              [7] S   [8] A   [9] B            cell-index increments dj*Ni + di
-//              [10] S  [11] A  [12] B           bit of the 3x3 Survive word (dj+1)*3 + (di+1)
+//              [10] S  [11] A  [12] B           bit of the neighbours' Survive byte (pack_kill9_kernel)
 // ---------------------------------------------------------------------------
 struct CrossTab { int v[4][16]; };
 
-__host__ inline void make_cross_tab(int Ni, CrossTab &t)
+__host__ inline void make_cross_tab(int Ni, CrossTab &t, int (*dji)[7][2] = nullptr)
 {
     // kc: 1 bottom, 2 right, 3 upper, 4 left.  (dj,di) of va, vb (the crossed edge's ends as F-points relative to F[jT,iT]),
     // of the two extension points, and of the straight / A / B destination cells -- the table of resolve_crossing above
@@ -245,12 +251,17 @@ __host__ inline void make_cross_tab(int Ni, CrossTab &t)
         r[1] = (vb[e][0] * Ni + vb[e][1]) * (int)sizeof(CellGeo);
         r[2] = (eA[e][0] * Ni + eA[e][1]) * (int)sizeof(CellGeo);
         r[3] = (eB[e][0] * Ni + eB[e][1]) * (int)sizeof(CellGeo);
+        if (dji) {
+            const int(*all[7])[2] = {va, vb, eA, eB, dS, dA, dB};
+            for (int q = 0; q < 7; q++) { dji[e][q][0] = all[q][e][0]; dji[e][q][1] = all[q][e][1]; }
+        }
         const int(*d[3])[2] = {dS, dA, dB};
         for (int q = 0; q < 3; q++) {
             const int dj = d[q][e][0], di = d[q][e][1];
             r[4 + q] = dj * 65536 + di;
             r[7 + q] = dj * Ni + di;
-            r[10 + q] = (dj + 1) * 3 + (di + 1);
+            const int b9 = (dj + 1) * 3 + (di + 1);
+            r[10 + q] = b9 < 4 ? b9 : b9 - 1;
         }
     }
 }
@@ -261,11 +272,11 @@ __device__ __forceinline__ pt geo_pt(const char *__restrict__ gb, unsigned off, 
     return *(const pt *)(gb + (size_t)off + (ptrdiff_t)imm);
 }
 
-// P1 -> P2 leaves the cell whose quad is (bl, br, ur, ul); k48 = byte offset of the cell's geometry record, kcell = its
-// index.  Returns the crossed edge kc (1..4) and fills the increments of the destination cell; `killed` = its Survive byte.
+// P1 -> P2 leaves the cell whose quad is (bl, br, ur, ul); k48 = byte offset of the cell's geometry record, k9 = the 3x3
+// Survive word of the cell for this record.  Returns the crossed edge kc (1..4) and fills the increments of the destination cell; `killed` = its Survive byte.
 // Same predicates on the same operands in the same order as resolve_crossing().
-__device__ __forceinline__ int resolve_crossing_tab(pt P1, pt P2, pt bl, pt br, pt ur, pt ul, unsigned k48, unsigned kcell,
-                                                    const char *__restrict__ gb, const uint16_t *__restrict__ kill9,
+__device__ __forceinline__ int resolve_crossing_tab(pt P1, pt P2, pt bl, pt br, pt ur, pt ul, unsigned k48, unsigned k9,
+                                                    const char *__restrict__ gb,
                                                     const int *__restrict__ tab /* LDS */, int &dcell, int &dk, bool &killed,
                                                     int *codes = nullptr)
 {
@@ -277,15 +288,18 @@ __device__ __forceinline__ int resolve_crossing_tab(pt P1, pt P2, pt bl, pt br, 
     const int *row = tab + 16 * (kc - 1);
     const int4 r0 = *(const int4 *)(row), r1 = *(const int4 *)(row + 4), r2 = *(const int4 *)(row + 8);
     const int bB = row[12];
-    // one batch of independent loads: the crossed edge's two ends, the two extension points, the 3x3 Survive word
+    // one batch of independent loads: the crossed edge's two ends and the two extension points
     const pt va = geo_pt(gb, k48 + (unsigned)r0.x), vb = geo_pt(gb, k48 + (unsigned)r0.y);
     const pt eA = geo_pt(gb, k48 + (unsigned)r0.z), eB = geo_pt(gb, k48 + (unsigned)r0.w);
-    const unsigned k9 = kill9[kcell];
     // NewHostCell (:217-243): first the side test of the two ends of the move against each prolongation ...
     bool hitA = ccw(P1, va, eA) != ccw(P2, va, eA);
     bool hitB = ccw(P1, vb, eB) != ccw(P2, vb, eB);
     // ... and only for lanes that pass it the second half of intersect2Seg (a diagonal move is rare: most waves skip this)
+#ifdef SITRK_NO_LAZY_HIT
+    {
+#else
     if (hitA || hitB) {
+#endif
         hitA = hitA && (ccw(P1, P2, va) != ccw(P1, P2, eA));
         hitB = hitB && (ccw(P1, P2, vb) != ccw(P1, P2, eB));
     }
@@ -451,8 +465,11 @@ struct RunArgs {
     StepArgs s;                         // s.u/s.v/s.kill unused; s.jrec = first record
     int nrec;
     const void *u[kMaxFuse], *v[kMaxFuse];
-    const uint16_t *kill9[kMaxFuse];    // 3x3 Survive words of each record (pack_kill9_kernel)
+    const uint8_t *kill9[kMaxFuse];     // the neighbours' Survive bits of each record, one byte per cell (pack_kill9_kernel)
+    const pt *geoF;                     // F-points alone, 16 B per cell (what the LDS patch is filled from)
     CrossTab tab;                       // crossing table (make_cross_tab), copied to LDS by every workgroup
+    int dji[4][7][2];                   // its (dj,di) pairs: va, vb, eA, eB, S, A, B per crossed edge (for the patch's own offsets)
+    int patch_cells, patch_margin;      // LDS patch: capacity in cells (0 = no patch) and the largest margin to try
 };
 
 // ---------------------------------------------------------------------------
@@ -488,36 +505,179 @@ __device__ __forceinline__ void load_ctx(const StepArgs &a, const char *__restri
     x.sFU = (ori & 2) != 0;             // ccw(F11, U10, U11)
 }
 
-template <typename FT, int UVS, bool WINDOW>
-__global__ __launch_bounds__(kBlock, 5) void advect_run_kernel(RunArgs ra)
+// ---------------------------------------------------------------------------
+// The F-point PATCH of a workgroup in LDS.
+// What bounds the fused loop (profiles/r02d_pmc_old_vs_table.txt, r02e A/B): neither VALU issue (58-80 % busy) nor HBM
+// (2.9 TB/s) but the CHAIN of dependent memory round trips every wave walks every record -- velocities of the (new) cell,
+// then the crossing path's extension points, then the new cell's context -- because nearly every wave has a buoy that
+// changes cell in every record; fewer instructions at the same chain length bought nothing (-29 % VALU, +9 % time).
+// Buoys are sorted by host cell, so a workgroup's 256 buoys sit in a compact patch of cells (one or two 8x16 tiles) and
+// move a few cells per launch: the patch's F-points (16 B per cell: a few KB, so occupancy is not touched) are copied
+// ONCE per launch into LDS, and CrossedEdge / NewHostCell / the new cell's quad read them with ds_read_b128 (two short
+// LDS hops instead of two global round trips).  The new cell's U/V points are then requested together with the next
+// record's velocities: one global round trip per record is left on the chain.  A buoy that leaves the patch (or a
+// workgroup whose buoys do not fit one: unsorted sets, the end of a tile row) reads global memory exactly as before.
+// ---------------------------------------------------------------------------
+struct Patch {
+    int R0, C0, PR, PC;                 // rows [R0, R0+PR) x columns [C0, C0+PC) of the mesh; PR = PC = 3: no patch (covers nothing)
+};
+
+// LDS byte offset of the F-point of cell (R0 + jr, C0 + ir)
+__device__ __forceinline__ unsigned patch_off(const Patch &pa, int jr, int ir) { return (unsigned)(jr * pa.PC + ir) * (unsigned)sizeof(pt); }
+
+// every F-point a buoy hosted by cell (R0+jr, C0+ir) can ask for -- its quad (rows jr-1..jr, columns ir-1..ir) and the
+// extension points of NewHostCell (rows jr-2..jr+1, columns ir-2..ir+1) -- lies inside the patch
+__device__ __forceinline__ bool patch_covers(const Patch &pa, int jr, int ir)
 {
-    __shared__ __attribute__((aligned(16))) int s_tab[64];
-    if (threadIdx.x < 64) s_tab[threadIdx.x] = ((const int *)&ra.tab)[threadIdx.x];
-    __syncthreads();                                     // the only barrier: before any lane can leave
+    return (unsigned)(jr - 2) < (unsigned)(pa.PR - 3) && (unsigned)(ir - 2) < (unsigned)(pa.PC - 3);
+}
+
+__device__ __forceinline__ pt lds_pt(const char *s_geo, unsigned off, int imm = 0) { return *(const pt *)(s_geo + off + imm); }
+
+// the context of cell `kcell`: its quad from the patch (LDS offset lo of its own F-point), the U/V points and the
+// orientation byte from global memory
+template <unsigned ES>
+__device__ __forceinline__ void load_ctx_lds(const StepArgs &a, const Patch &pa, const char *s_geo, const char *__restrict__ gb,
+                                             unsigned kcell, unsigned lo, CellCtx &x)
+{
+    const unsigned Ni = (unsigned)a.Ni;
+    x.o1 = kcell * ES; x.o0 = (kcell - Ni) * ES;
+    const unsigned k48 = kcell * (unsigned)sizeof(CellGeo), k48b = k48 - Ni * (unsigned)sizeof(CellGeo);
+    x.U11 = geo_pt(gb, k48, 16); x.V11 = geo_pt(gb, k48, 32); x.U10 = geo_pt(gb, k48, -32); x.V01 = geo_pt(gb, k48b, 32);
+    const int8_t ori = a.orient[kcell];
+    const unsigned lob = lo - (unsigned)pa.PC * (unsigned)sizeof(pt);
+    x.F11 = lds_pt(s_geo, lo, 0); x.F10 = lds_pt(s_geo, lo, -16);
+    x.F01 = lds_pt(s_geo, lob, 0); x.F00 = lds_pt(s_geo, lob, -16);
+    x.sFV = (ori & 1) != 0;
+    x.sFU = (ori & 2) != 0;
+}
+
+// resolve_crossing_tab() with every point read from the patch: same predicates, same operands, same order.
+// tabL row kc-1: [0] va [1] vb [2] eA [3] eB  LDS byte offsets relative to the host cell's record; [4] S [5] A [6] B
+// LDS byte increments to the destination cell's record
+__device__ __forceinline__ void resolve_crossing_lds(pt P1, pt P2, pt bl, pt br, pt ur, pt ul, unsigned lo, unsigned k9, const char *s_geo,
+                                                     const int *__restrict__ tab, const int *__restrict__ tabL, int &dcell, int &dk,
+                                                     int &dlo, bool &killed)
+{
+    const bool sbl = ccw(P1, P2, bl), sbr = ccw(P1, P2, br), sur = ccw(P1, P2, ur), sul = ccw(P1, P2, ul);
+    const bool h1 = (ccw(P1, bl, br) != ccw(P2, bl, br)) && (sbl != sbr);
+    const bool h2 = (ccw(P1, br, ur) != ccw(P2, br, ur)) && (sbr != sur);
+    const bool h3 = (ccw(P1, ur, ul) != ccw(P2, ur, ul)) && (sur != sul);
+    const int kc = h1 ? 1 : (h2 ? 2 : (h3 ? 3 : 4));
+    const int *row = tab + 16 * (kc - 1), *rowL = tabL + 8 * (kc - 1);
+    const int4 r1 = *(const int4 *)(row + 4), r2 = *(const int4 *)(row + 8);
+    const int bB = row[12];
+    const int4 l0 = *(const int4 *)(rowL), l1 = *(const int4 *)(rowL + 4);
+    const pt va = lds_pt(s_geo, lo + (unsigned)l0.x), vb = lds_pt(s_geo, lo + (unsigned)l0.y);
+    const pt eA = lds_pt(s_geo, lo + (unsigned)l0.z), eB = lds_pt(s_geo, lo + (unsigned)l0.w);
+    bool hitA = ccw(P1, va, eA) != ccw(P2, va, eA);
+    bool hitB = ccw(P1, vb, eB) != ccw(P2, vb, eB);
+    if (hitA || hitB) {
+        hitA = hitA && (ccw(P1, P2, va) != ccw(P1, P2, eA));
+        hitB = hitB && (ccw(P1, P2, vb) != ccw(P1, P2, eB));
+    }
+    dcell = hitA ? r1.y : (hitB ? r1.z : r1.x);
+    dk = hitA ? r2.x : (hitB ? r2.y : r1.w);
+    dlo = hitA ? l1.y : (hitB ? l1.z : l1.x);
+    const int bit = hitA ? r2.w : (hitB ? bB : r2.z);
+    killed = ((k9 >> bit) & 1u) != 0;
+}
+
+static constexpr int kRunLdsFixed = 256 + 128 + 64 + 256;   // crossing table, its LDS-offset twin, bounding box / patch header,
+                                                            // dump area of the prefetches (256 B = one dword per lane)
+
+#ifndef SITRK_RUN_WAVES
+#define SITRK_RUN_WAVES 6               // <= 80 VGPRs (28 B of scratch): 6 waves per SIMD measured 7 % faster than 5 without spills,
+#endif                                  // 7 waves (72 VGPRs, 44 B) 25 % slower
+template <typename FT, int UVS, bool WINDOW>
+__global__ __launch_bounds__(kBlock, SITRK_RUN_WAVES) void advect_run_kernel(RunArgs ra)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *s_tab = (int *)smem;                            // CrossTab, 64 ints
+    int *s_tabL = s_tab + 64;                            // 4 x 8 ints
+    int *s_box = s_tabL + 32;                            // [0..3] jmin jmax imin imax of the live buoys; [4..7] R0 C0 PR PC
     const StepArgs &a = ra.s;
     const unsigned blk = (a.tune & TUNE_XCD_REMAP) ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
     const int64_t p = (int64_t)blk * kBlock + threadIdx.x;
-    if (p >= a.nP) return;
     const bool nt = (a.tune & TUNE_NT_STATE) != 0;
-    int32_t c = nt ? __builtin_nontemporal_load(&a.cell[p]) : a.cell[p];
-    if (c < 0) return;                                   // iAlive != 1 (:380)
+    int32_t c = -1;
+    if (p < a.nP) c = nt ? __builtin_nontemporal_load(&a.cell[p]) : a.cell[p];
+    const bool live = c >= 0;                            // iAlive == 1 (:380)
+    if (threadIdx.x < 64) s_tab[threadIdx.x] = ((const int *)&ra.tab)[threadIdx.x];
+    if (threadIdx.x == 0) { s_box[0] = 0x7fffffff; s_box[1] = -1; s_box[2] = 0x7fffffff; s_box[3] = -1; }
+    __syncthreads();
+    // ---- the workgroup's patch: bounding box of its live buoys' host cells, widened by the stencil and by as many
+    //      cells of margin as the LDS budget allows (a buoy moves < 1 cell per record)
+    {
+        int jlo = live ? cell_j(c) : 0x7fffffff, jhi = live ? cell_j(c) : -1, ilo = live ? cell_i(c) : 0x7fffffff, ihi = live ? cell_i(c) : -1;
+        for (int off = 32; off > 0; off >>= 1) {
+            jlo = min(jlo, __shfl_xor(jlo, off)); jhi = max(jhi, __shfl_xor(jhi, off));
+            ilo = min(ilo, __shfl_xor(ilo, off)); ihi = max(ihi, __shfl_xor(ihi, off));
+        }
+        if ((threadIdx.x & 63) == 0 && jhi >= 0) {
+            atomicMin(&s_box[0], jlo); atomicMax(&s_box[1], jhi); atomicMin(&s_box[2], ilo); atomicMax(&s_box[3], ihi);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int R0 = 0, C0 = 0, PR = 3, PC = 3;              // "no patch": patch_covers() is false for every cell
+        if (s_box[1] >= 0 && ra.patch_cells > 0) {
+            const int nr = s_box[1] - s_box[0] + 1 + 3, nc = s_box[3] - s_box[2] + 1 + 3;      // rows jmin-2 .. jmax+1
+            int m = -1;
+            for (int t = 0; t <= ra.patch_margin; t++)
+                if ((int64_t)(nr + 2 * t) * (nc + 2 * t) <= ra.patch_cells) m = t;
+            if (m >= 0) {
+                R0 = max(0, s_box[0] - 2 - m); C0 = max(0, s_box[2] - 2 - m);
+                PR = min(a.Nj, s_box[1] + 2 + m) - R0; PC = min(a.Ni, s_box[3] + 2 + m) - C0;
+            }
+        }
+        s_box[4] = R0; s_box[5] = C0; s_box[6] = PR; s_box[7] = PC;
+    }
+    __syncthreads();
+    Patch pa;
+    pa.R0 = s_box[4]; pa.C0 = s_box[5]; pa.PR = s_box[6]; pa.PC = s_box[7];
+    char *s_geo = smem + kRunLdsFixed;
+    float *s_dump = (float *)(smem + 256 + 128 + 64);
+    if (threadIdx.x < 28) {
+        // LDS twins of the table's geometry offsets: (dj*PC + di) * 16 for va, vb, eA, eB, S, A, B of each crossed edge
+        const int e = threadIdx.x / 7, q = threadIdx.x % 7;
+        s_tabL[8 * e + q] = (ra.dji[e][q][0] * pa.PC + ra.dji[e][q][1]) * (int)sizeof(pt);
+    }
+    const char *__restrict__ gb = (const char *)a.geo;
+    if (pa.PR > 3) {
+        // a row of the patch is contiguous in the F-only copy of the geometry
+        const int ncell = pa.PR * pa.PC;
+        for (int t = threadIdx.x; t < ncell; t += kBlock) {
+            const int r = t / pa.PC, cc = t - r * pa.PC;
+            *(v2d *)(s_geo + (size_t)t * sizeof(pt)) = *(const v2d *)(ra.geoF + ((size_t)(pa.R0 + r) * a.Ni + pa.C0 + cc));
+        }
+    }
+    __syncthreads();                                     // last barrier: from here on lanes may leave
+    if (!live) return;
     int first = 0, last = 0x7fffffff;
     if (WINDOW) { first = a.first[p]; last = a.last[p]; }
     pt P = nt ? load_pt_nt(&a.pos[p]) : a.pos[p];
     const int32_t c0 = c;
-    const char *__restrict__ gb = (const char *)a.geo;
     bool moved = false;
     CellCtx x;
-    load_ctx<sizeof(FT)>(a, gb, (unsigned)(cell_j(c) * a.Ni + cell_i(c)), x);
+    // position of the host cell inside the patch, packed like the cell itself (jr << 16 | ir), and the LDS offset of its record
+    int crel = c - ((pa.R0 << 16) | pa.C0);
+    unsigned lo = patch_off(pa, crel >> 16, crel & 0xffff);
+    bool inl = patch_covers(pa, crel >> 16, crel & 0xffff);
+    {
+        const unsigned kcell = (unsigned)(cell_j(c) * a.Ni + cell_i(c));
+        if (inl) load_ctx_lds<sizeof(FT)>(a, pa, s_geo, gb, kcell, lo, x);
+        else load_ctx<sizeof(FT)>(a, gb, kcell, x);
+    }
     // the record pointers (scalar loads from the kernel arguments) are fetched one record ahead: a record's vector
     // loads go out at the top of its iteration instead of behind a scalar load and its wait (-0.7 %)
-    const char *ub_next = (const char *)ra.u[0], *vb_next = (const char *)ra.v[0];
+    const char *ub_next = (const char *)ra.u[0], *vb_next = (const char *)ra.v[0], *kb_next = (const char *)ra.kill9[0];
 #pragma unroll 1
     for (int r = 0; r < ra.nrec; r++) {
         const int jrec = a.jrec + r;
-        const char *ub = ub_next, *vb = vb_next;
+        const char *ub = ub_next, *vb = vb_next, *kb = kb_next;
         const int rn = (r + 1 < ra.nrec) ? r + 1 : r;
-        ub_next = (const char *)ra.u[rn]; vb_next = (const char *)ra.v[rn];
+        ub_next = (const char *)ra.u[rn]; vb_next = (const char *)ra.v[rn]; kb_next = (const char *)ra.kill9[rn];
         if (WINDOW) {
             if (jrec < first) continue;
             if (jrec > last) break;
@@ -525,6 +685,21 @@ __global__ __launch_bounds__(kBlock, 5) void advect_run_kernel(RunArgs ra)
         // the four velocity candidates u[jT,iT-1], u[jT,iT], v[jT-1,iT], v[jT,iT]
         FT fu0 = *(const FT *)(ub + x.o1 - sizeof(FT)), fu1 = *(const FT *)(ub + x.o1);
         FT fv0 = *(const FT *)(vb + x.o0), fv1 = *(const FT *)(vb + x.o1);
+        // ... and the cell's 3x3 Survive word of this record (used only if the buoy leaves the cell)
+        unsigned k9 = *(const uint8_t *)(kb + (x.o1 >> (sizeof(FT) == 4 ? 2 : 3)));
+        if ((a.tune & TUNE_PREFETCH) && r + 2 < ra.nrec) {
+            // A record's fields are new to every cache: the first wave to touch a line waits for HBM.  Touch the lines
+            // of the record after next now (a buoy moves < 1 cell per record: nearly always the same lines), with loads
+            // that need no register and that nobody waits for: LDS-DMA into a dump area.  Buoys are sorted by cell, so
+            // a few lanes spread over the wave reach nearly all of its lines (TUNE_PREFETCH_V0: every lane does).
+            const bool mine = (a.tune & TUNE_PREFETCH_V0) || (threadIdx.x & 15) == 0 || (threadIdx.x & 63) == 63;
+            if (mine) {
+                const char *up = (const char *)ra.u[r + 2], *vp = (const char *)ra.v[r + 2], *kp = (const char *)ra.kill9[r + 2];
+                __builtin_amdgcn_global_load_lds((const unsigned *)(up + x.o1), s_dump, 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((const unsigned *)(vp + x.o1), s_dump, 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((const unsigned *)(kp + ((x.o1 >> (sizeof(FT) == 4 ? 2 : 3)) & ~3u)), s_dump, 4, 0, 0);
+            }
+        }
         double zU, zV;
         if (UVS == 0) {                                  // :423-425
             zU = 0.5 * ((double)fu1 + (double)fu0);
@@ -550,24 +725,45 @@ __global__ __launch_bounds__(kBlock, 5) void advect_run_kernel(RunArgs ra)
         bool killed = false;
         if (!SITRK_INSIDE(Pn.y, Pn.x, x.F00, x.F01, x.F11, x.F10, a.eps_mg)) {      // :466-484
             const unsigned kcell = x.o1 / (unsigned)sizeof(FT);
-            int dcell, dk;
-            resolve_crossing_tab(P, Pn, x.F00, x.F01, x.F11, x.F10, kcell * (unsigned)sizeof(CellGeo), kcell, gb, ra.kill9[r], s_tab,
-                                 dcell, dk, killed);
+            int dcell, dk, dlo = 0;
+            pin_load(k9);
+            if (inl) {
+                resolve_crossing_lds(P, Pn, x.F00, x.F01, x.F11, x.F10, lo, k9, s_geo, s_tab, s_tabL, dcell, dk, dlo, killed);
+            } else {
+                resolve_crossing_tab(P, Pn, x.F00, x.F01, x.F11, x.F10, kcell * (unsigned)sizeof(CellGeo), k9, gb, s_tab, dcell, dk, killed);
+            }
             c += dcell;
-            if (!killed) load_ctx<sizeof(FT)>(a, gb, kcell + (unsigned)dk, x);
+            crel += dcell;
+            // (a killed buoy's destination is inside the mesh too: its context is loaded unconditionally, which keeps the
+            // loads out of the shadow of the Survive test)
+            if (inl) {
+                lo += (unsigned)dlo;
+            } else {
+                lo = patch_off(pa, crel >> 16, crel & 0xffff);
+            }
+            inl = patch_covers(pa, crel >> 16, crel & 0xffff);
+            if (inl) load_ctx_lds<sizeof(FT)>(a, pa, s_geo, gb, kcell + (unsigned)dk, lo, x);
+            else load_ctx<sizeof(FT)>(a, gb, kcell + (unsigned)dk, x);
         }
         P = Pn;
         if (killed) {
             c |= SITRK_DEAD_BIT;
-            a.kill_rec[p] = jrec;
+            unsigned tk = threadIdx.x;
+            asm volatile("" : "+v"(tk));
+            a.kill_rec[(int64_t)blk * kBlock + tk] = jrec;
             break;                                       // dead buoys never step again
         }
     }
+    // (the buoy's index is recomputed here rather than kept: 16 bytes of state addresses per lane would be spilled to
+    // scratch across the loop, i.e. written and read back through HBM)
+    unsigned tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int64_t pe = (int64_t)blk * kBlock + tid;
     if (moved) {
-        if (nt) store_pt_nt(&a.pos[p], P);
-        else a.pos[p] = P;
+        if (nt) store_pt_nt(&a.pos[pe], P);
+        else a.pos[pe] = P;
     }
-    if (c != c0) a.cell[p] = c;
+    if (c != c0) a.cell[pe] = c;
 }
 
 #ifdef SITRK_DIAG
@@ -679,9 +875,8 @@ __global__ void eval_crossing_kernel(int64_t n, int Nj, int Ni, const CellGeo *_
     if (jT >= 2 && iT >= 2 && (size_t)Nj * Ni * sizeof(CellGeo) < ((size_t)1 << 32)) {
         int dcell, dk, codes2[2];
         bool killed2;
-        // (zero_mask is all zeros: read as 16-bit words it is a valid "nothing kills" 3x3 word array of half the length)
-        resolve_crossing_tab(P1[p], P2[p], bl, br, ur, ul, (unsigned)k * (unsigned)sizeof(CellGeo), (unsigned)k / 2u, (const char *)geo,
-                             (const uint16_t *)zero_mask, s_tab, dcell, dk, killed2, codes2);
+        resolve_crossing_tab(P1[p], P2[p], bl, br, ur, ul, (unsigned)k * (unsigned)sizeof(CellGeo), 0u, (const char *)geo,
+                             s_tab, dcell, dk, killed2, codes2);
         const int32_t cn2 = pack_cell(jT, iT) + dcell;
         const bool same = (cn2 == cn) && (codes2[0] == codes[0]) && (codes2[1] == codes[1]) && !killed2 &&
                           ((int64_t)k + dk == (int64_t)cell_j(cn) * Ni + cell_i(cn));

@@ -1,18 +1,19 @@
 #!/bin/bash
-# A/B timing of alternative builds of libsitrk.so on the GPU box (via gpurun): each build_ab/libsitrk_<tag>.so is
-# copied over sitrack_amd/libsitrk.so in the box's scratch copy and bench.py is run with it.
-# Usage: tools/ab_libs.sh <out-prefix> <tag> [<tag> ...]   -> gpurun_out/<out-prefix>_<tag>.json
-set -o pipefail
-PFX=$1; shift
-cp sitrack_amd/libsitrk.so /tmp/libsitrk_orig.so
-for tag in "$@"; do
-  cp build_ab/libsitrk_$tag.so sitrack_amd/libsitrk.so || exit 1
-  python3 bench.py --no-cpu-baseline $AB_ARGS > gpurun_out/${PFX}_$tag.json 2> gpurun_out/${PFX}_$tag.err || { tail -5 gpurun_out/${PFX}_$tag.err; exit 1; }
-  python3 - "$tag" gpurun_out/${PFX}_$tag.json <<'PY'
-import json, sys
-d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
-p = d.get("per_record_launch", {})
-print("%-10s fused %.4e (%.4f ms/record)   per-record %.4e (%.4f ms)" % (sys.argv[1], d["value"], d["ms_per_step"], p.get("value", 0), p.get("ms_per_step", 0)), flush=True)
+# Runs on the GPU box: bench.py once per variant library in build_ab/ (tools/build_variant.sh), interleaved over ROUNDS rounds.
+#   tools/ab_libs.sh <tag> "<variant names>" [bench args...]
+TAG=$1; VARS=$2; shift 2
+ARGS=${@:---steps 640 --warmup 64 --no-cpu-baseline --no-c2}
+mkdir -p gpurun_out
+for r in 1 2; do
+  for v in $VARS; do
+    SITRK_LIB_PATH=$PWD/build_ab/libsitrk_$v.so python bench.py $ARGS > gpurun_out/${TAG}_${v}_$r.json 2> gpurun_out/${TAG}_${v}_$r.err || { echo "$v failed"; tail -3 gpurun_out/${TAG}_${v}_$r.err; }
+    python - <<PY
+import json
+try:
+    d=json.loads(open("gpurun_out/${TAG}_${v}_$r.json").read().strip().splitlines()[-1])
+    print("%-12s round $r  fused %.4e  (%.3f ms/launch)  per-record %.4e" % ("$v", d["value"], d["roofline"]["avg_launch_ms"], d.get("per_record_launch",{}).get("value",0)))
+except Exception as e:
+    print("$v", "no result", e)
 PY
+  done
 done
-cp /tmp/libsitrk_orig.so sitrack_amd/libsitrk.so
