@@ -223,8 +223,6 @@ SITRK_API int sitrk_set_tuning(sitrk_t *h, const char *knob, int value)
     int bit = 0;
     if (!strcmp(knob, "xcd_remap")) bit = TUNE_XCD_REMAP;
     else if (!strcmp(knob, "nt_state")) bit = TUNE_NT_STATE;
-    else if (!strcmp(knob, "prefetch")) bit = TUNE_PREFETCH;
-    else if (!strcmp(knob, "prefetch_v0")) bit = TUNE_PREFETCH_V0;
     else if (!strcmp(knob, "step_block")) {          // workgroup size of advect_step_kernel
         if (value != 256 && value != 512 && value != 1024) return fail(h, SITRK_EINVAL, "sitrk_set_tuning: step_block must be 256, 512 or 1024");
         h->step_block = value;
@@ -244,6 +242,11 @@ SITRK_API int sitrk_set_tuning(sitrk_t *h, const char *knob, int value)
     else if (!strcmp(knob, "patch_kb")) {            // LDS bytes (KiB) per workgroup for the fused kernel's geometry patch
         if (value < 0 || value > 63) return fail(h, SITRK_EINVAL, "sitrk_set_tuning: patch_kb must be 0..63");
         h->patch_kb = value;
+        return SITRK_OK;
+    }
+    else if (!strcmp(knob, "xcd_group")) {
+        if (value < 0 || value > 4096) return fail(h, SITRK_EINVAL, "sitrk_set_tuning: xcd_group must be 0..4096");
+        h->xcd_group = value;
         return SITRK_OK;
     }
     else if (!strcmp(knob, "patch_margin")) {
@@ -764,6 +767,7 @@ SITRK_API int sitrk_run(sitrk_t *h, int slot0, int jrec0, int nsteps)
         ra.geoF = h->geoF;
         ra.patch_cells = (int)((size_t)h->patch_kb * 1024 / sizeof(pt));
         ra.patch_margin = h->patch_margin;
+        ra.xcd_group = h->xcd_group;
         int used[kMaxFuse];
         for (int r = 0; r < m; r++) {
             const int slot = (slot0 + k + r) % h->nslots;

@@ -162,8 +162,6 @@ enum : int {
     TUNE_XCD_REMAP = 1,            // give each XCD a contiguous chunk of the sorted buoys
     TUNE_NT_STATE = 2,             // non-temporal loads/stores for the once-per-step pos/cell streams
     TUNE_LOCATE_BRUTEFORCE = 8,    // SeedInit: whole-grid Haversine scan per seed (the reference's algorithm)
-    TUNE_PREFETCH = 64,            // fused kernel: touch the lines of the velocities two records ahead (LDS-DMA into a dump area)
-    TUNE_PREFETCH_V0 = 128,        // ... including the row below (v[jT-1,iT])
     TUNE_DIAG_MEMONLY = 16,        // ablation kernels, diagnostic builds only (make DIAG=1)
     TUNE_DIAG_NOCROSS = 32,
 };

@@ -62,6 +62,7 @@ struct sitrk_ctx {
     int fuse = 32;                      // sitrk_run: consecutive resident records advanced per launch, <= nslots (1 = one launch per record)
     int tile_j = 8, tile_i = 16;        // sort order: 0 = row-major cells, else tile-major tiles of tile_j x tile_i cells
     int patch_kb = 16;                  // fused kernel: LDS bytes per workgroup for its geometry patch (0 = none, all reads global)
+    int xcd_group = 16;                 // fused kernel: runs of that many consecutive workgroups on one XCD (0/1 = hardware order)
     int patch_margin = 8;               // ... and the widest margin of cells around the buoys' bounding box it may take
 
     // records

@@ -339,6 +339,16 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
+// The same idea at a finer grain: runs of `g` consecutive workgroups (neighbouring tiles, which share 128-byte lines of
+// the fields) go to one XCD, the runs themselves stay dealt round-robin so that all HBM channels see one stream.
+__device__ __forceinline__ unsigned xcd_group(unsigned bid, unsigned nwg, unsigned g)
+{
+    const unsigned span = 8u * g, full = (nwg / span) * span;
+    if (bid >= full) return bid;
+    const unsigned base = (bid / span) * span, r = bid - base;       // r = position inside a span of 8 runs
+    return base + (r & 7u) * g + (r >> 3);                            // hardware deals r round-robin: XCD = r & 7
+}
+
 // The fused loop evaluates `/1000.` and IsInsideQuadrangle without fp64 divisions (sitrk_geom.h: div1000,
 // inside_quad_hot - same results for every input): 0.111 -> 0.101 ms per record on C3.  The one-record kernel is
 // bound by memory latency, not by issue, and was measured 4-6 % SLOWER with them (and with pinned loads): it keeps
@@ -470,6 +480,7 @@ struct RunArgs {
     CrossTab tab;                       // crossing table (make_cross_tab), copied to LDS by every workgroup
     int dji[4][7][2];                   // its (dj,di) pairs: va, vb, eA, eB, S, A, B per crossed edge (for the patch's own offsets)
     int patch_cells, patch_margin;      // LDS patch: capacity in cells (0 = no patch) and the largest margin to try
+    int xcd_group;                      // > 1: runs of that many consecutive workgroups share an XCD
 };
 
 // ---------------------------------------------------------------------------
@@ -583,8 +594,7 @@ __device__ __forceinline__ void resolve_crossing_lds(pt P1, pt P2, pt bl, pt br,
     killed = ((k9 >> bit) & 1u) != 0;
 }
 
-static constexpr int kRunLdsFixed = 256 + 128 + 64 + 256;   // crossing table, its LDS-offset twin, bounding box / patch header,
-                                                            // dump area of the prefetches (256 B = one dword per lane)
+static constexpr int kRunLdsFixed = 256 + 128 + 64;      // crossing table, its LDS-offset twin, bounding box / patch header
 
 #ifndef SITRK_RUN_WAVES
 #define SITRK_RUN_WAVES 6               // <= 80 VGPRs (28 B of scratch): 6 waves per SIMD measured 7 % faster than 5 without spills,
@@ -597,7 +607,8 @@ __global__ __launch_bounds__(kBlock, SITRK_RUN_WAVES) void advect_run_kernel(Run
     int *s_tabL = s_tab + 64;                            // 4 x 8 ints
     int *s_box = s_tabL + 32;                            // [0..3] jmin jmax imin imax of the live buoys; [4..7] R0 C0 PR PC
     const StepArgs &a = ra.s;
-    const unsigned blk = (a.tune & TUNE_XCD_REMAP) ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const unsigned blk = (a.tune & TUNE_XCD_REMAP) ? xcd_remap(blockIdx.x, gridDim.x)
+                         : (ra.xcd_group > 1 ? xcd_group(blockIdx.x, gridDim.x, (unsigned)ra.xcd_group) : blockIdx.x);
     const int64_t p = (int64_t)blk * kBlock + threadIdx.x;
     const bool nt = (a.tune & TUNE_NT_STATE) != 0;
     int32_t c = -1;
@@ -637,7 +648,6 @@ __global__ __launch_bounds__(kBlock, SITRK_RUN_WAVES) void advect_run_kernel(Run
     Patch pa;
     pa.R0 = s_box[4]; pa.C0 = s_box[5]; pa.PR = s_box[6]; pa.PC = s_box[7];
     char *s_geo = smem + kRunLdsFixed;
-    float *s_dump = (float *)(smem + 256 + 128 + 64);
     if (threadIdx.x < 28) {
         // LDS twins of the table's geometry offsets: (dj*PC + di) * 16 for va, vb, eA, eB, S, A, B of each crossed edge
         const int e = threadIdx.x / 7, q = threadIdx.x % 7;
@@ -687,19 +697,6 @@ __global__ __launch_bounds__(kBlock, SITRK_RUN_WAVES) void advect_run_kernel(Run
         FT fv0 = *(const FT *)(vb + x.o0), fv1 = *(const FT *)(vb + x.o1);
         // ... and the cell's 3x3 Survive word of this record (used only if the buoy leaves the cell)
         unsigned k9 = *(const uint8_t *)(kb + (x.o1 >> (sizeof(FT) == 4 ? 2 : 3)));
-        if ((a.tune & TUNE_PREFETCH) && r + 2 < ra.nrec) {
-            // A record's fields are new to every cache: the first wave to touch a line waits for HBM.  Touch the lines
-            // of the record after next now (a buoy moves < 1 cell per record: nearly always the same lines), with loads
-            // that need no register and that nobody waits for: LDS-DMA into a dump area.  Buoys are sorted by cell, so
-            // a few lanes spread over the wave reach nearly all of its lines (TUNE_PREFETCH_V0: every lane does).
-            const bool mine = (a.tune & TUNE_PREFETCH_V0) || (threadIdx.x & 15) == 0 || (threadIdx.x & 63) == 63;
-            if (mine) {
-                const char *up = (const char *)ra.u[r + 2], *vp = (const char *)ra.v[r + 2], *kp = (const char *)ra.kill9[r + 2];
-                __builtin_amdgcn_global_load_lds((const unsigned *)(up + x.o1), s_dump, 4, 0, 0);
-                __builtin_amdgcn_global_load_lds((const unsigned *)(vp + x.o1), s_dump, 4, 0, 0);
-                __builtin_amdgcn_global_load_lds((const unsigned *)(kp + ((x.o1 >> (sizeof(FT) == 4 ? 2 : 3)) & ~3u)), s_dump, 4, 0, 0);
-            }
-        }
         double zU, zV;
         if (UVS == 0) {                                  // :423-425
             zU = 0.5 * ((double)fu1 + (double)fu0);
