@@ -1,11 +1,16 @@
-"""Read-only access to NetCDF-4 (= HDF5) files through the system's libhdf5, for installations without the `netCDF4`
-Python package (this image has none; it has HDF5 1.10 under /opt/conda/lib).
+"""NetCDF-4 (= HDF5) files through the system's libhdf5, for installations without the `netCDF4` Python package (this
+image has none; it has HDF5 1.10 under /opt/conda/lib): a reader for NEMO / seeding inputs and a writer (`NC4Writer`)
+for the trajectory / seeding files of reference `sitrack/ncio.py:131-197`.
 
 NEMO's mesh_mask and SI3 output files and the reference's seeding files (`sitrack/ncio.py`, netCDF4.Dataset) are HDF5
 files whose variables are plain datasets and whose dimensions are datasets of the same name; reading them needs ~20
 calls of the HDF5 C API, bound here with ctypes.  Only what `ncio._Reader` asks for: existence, shapes, numeric
 datasets (whole, or a leading-index / slice selection read as a hyperslab so that one record of a multi-GB file is one
-read), numeric and string attributes.  Nothing is written: outputs go through netCDF4 when present, NetCDF-3 otherwise.
+read), numeric and string attributes.  Writing: `NC4Writer` lays a file out the way netCDF-C does -- every dimension a dimension-scale dataset (H5DS, from
+libhdf5_hl), every variable a chunked dataset attached to its scales, unlimited leading dimension, shuffle + deflate,
+`_FillValue` as a one-element attribute plus the dataset's own fill value, fixed-length string attributes -- so that
+`netCDF4` / `ncdump` read it as a NetCDF-4 file (`h5dump -H` of an output equals the header of the reference's own
+`tools/nc/...HSS5.nc__KEEP`, tests/test_driver.py).
 """
 import ctypes as C
 import ctypes.util
@@ -268,3 +273,194 @@ class H5File:
                 self.L.H5Aclose(a)
         finally:
             self.L.H5Dclose(d)
+
+
+# --------------------------------------------------------------------------- writer
+_HL = None
+UNLIMITED = 2 ** 64 - 1
+
+
+def _load_hl():
+    """libhdf5_hl (dimension scales), from the directory libhdf5 itself was loaded from"""
+    global _HL
+    if _HL is not None:
+        return _HL
+    L = _load()
+    cands = [os.environ.get("SITRK_LIBHDF5_HL")]
+    base = getattr(L, "_name", "") or ""
+    if base and os.path.sep in base:
+        cands.append(os.path.join(os.path.dirname(base), "libhdf5_hl.so"))
+    cands += [ctypes.util.find_library("hdf5_hl"), "/opt/conda/lib/libhdf5_hl.so", "/usr/lib/x86_64-linux-gnu/libhdf5_serial_hl.so",
+              "libhdf5_hl.so"]
+    err = None
+    for c in cands:
+        if not c:
+            continue
+        try:
+            H = C.CDLL(c)
+            H.H5DSset_scale.restype, H.H5DSset_scale.argtypes = C.c_int, [hid_t, C.c_char_p]
+            H.H5DSattach_scale.restype, H.H5DSattach_scale.argtypes = C.c_int, [hid_t, hid_t, C.c_uint]
+            _HL = H
+            return H
+        except (OSError, AttributeError) as e:
+            err = e
+    raise H5Unavailable("no usable libhdf5_hl (dimension scales): %s" % err)
+
+
+def writer_available():
+    try:
+        _load()
+        _load_hl()
+        return True
+    except H5Unavailable:
+        return False
+
+
+def _wlib():
+    L = _load()
+    if getattr(L, "_w_ready", False):
+        return L
+    sig = {
+        "H5Fcreate": (hid_t, [C.c_char_p, C.c_uint, hid_t, hid_t]),
+        "H5Pcreate": (hid_t, [hid_t]), "H5Pclose": (C.c_int, [hid_t]),
+        "H5Pset_chunk": (C.c_int, [hid_t, C.c_int, C.POINTER(hsize_t)]),
+        "H5Pset_deflate": (C.c_int, [hid_t, C.c_uint]), "H5Pset_shuffle": (C.c_int, [hid_t]),
+        "H5Pset_fill_value": (C.c_int, [hid_t, hid_t, C.c_void_p]),
+        "H5Pset_attr_creation_order": (C.c_int, [hid_t, C.c_uint]),
+        "H5Pset_link_creation_order": (C.c_int, [hid_t, C.c_uint]),
+        "H5Dcreate2": (hid_t, [hid_t, C.c_char_p, hid_t, hid_t, hid_t, hid_t, hid_t]),
+        "H5Dwrite": (C.c_int, [hid_t, hid_t, hid_t, hid_t, hid_t, C.c_void_p]),
+        "H5Screate": (hid_t, [C.c_int]),
+        "H5Acreate2": (hid_t, [hid_t, C.c_char_p, hid_t, hid_t, hid_t, hid_t]),
+        "H5Awrite": (C.c_int, [hid_t, hid_t, C.c_void_p]),
+        "H5Gopen2": (hid_t, [hid_t, C.c_char_p, hid_t]), "H5Gclose": (C.c_int, [hid_t]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    L._dcpl_class = hid_t.in_dll(L, "H5P_CLS_DATASET_CREATE_ID_g").value
+    L._fcpl_class = hid_t.in_dll(L, "H5P_CLS_FILE_CREATE_ID_g").value
+    L._std = {k: hid_t.in_dll(L, "H5T_%s_g" % v).value for k, v in
+              (("i1", "STD_I8LE"), ("u1", "STD_U8LE"), ("i2", "STD_I16LE"), ("i4", "STD_I32LE"), ("i8", "STD_I64LE"),
+               ("f4", "IEEE_F32LE"), ("f8", "IEEE_F64LE"))}
+    L._w_ready = True
+    return L
+
+
+class NC4Writer:
+    """One NetCDF-4 file: createDimension / createVariable / attributes, in the vocabulary of netCDF4.Dataset (only what
+    ncSaveCloudBuoys needs).  Variables are written whole with write()."""
+
+    def __init__(self, path):
+        self.L, self.H = _wlib(), _load_hl()
+        L = self.L
+        # netCDF-C tracks creation order of links and attributes (ncdump lists variables in that order)
+        fcpl = L.H5Pcreate(L._fcpl_class)
+        L.H5Pset_link_creation_order(fcpl, 3)                     # H5P_CRT_ORDER_TRACKED | INDEXED
+        L.H5Pset_attr_creation_order(fcpl, 3)
+        self.fid = L.H5Fcreate(os.fsencode(path), 2, fcpl, 0)      # H5F_ACC_TRUNC
+        L.H5Pclose(fcpl)
+        if self.fid < 0:
+            raise OSError("H5Fcreate(%s) failed" % path)
+        self.dims = {}                   # name -> (size, unlimited, dimid)
+        self.vars = {}                   # name -> (hid, dtype key, dim names)
+
+    # -- attributes
+    def _attr(self, obj, name, val):
+        L = self.L
+        if isinstance(val, (str, bytes)):
+            b = val.encode() if isinstance(val, str) else val
+            t = L.H5Tcopy(L._c_s1)
+            L.H5Tset_size(t, max(len(b), 1))
+            sp = L.H5Screate(0)                                     # H5S_SCALAR
+            a = L.H5Acreate2(obj, name.encode(), t, sp, 0, 0)
+            buf = C.create_string_buffer(b, max(len(b), 1))
+            ok = a >= 0 and L.H5Awrite(a, t, buf) >= 0
+            L.H5Aclose(a); L.H5Sclose(sp); L.H5Tclose(t)
+        else:
+            v = np.atleast_1d(np.asarray(val))
+            key = v.dtype.kind + str(v.dtype.itemsize)
+            sp = L.H5Screate_simple(1, (hsize_t * 1)(v.size), None) if name != "_Netcdf4Dimid" else L.H5Screate(0)
+            a = L.H5Acreate2(obj, name.encode(), L._std[key], sp, 0, 0)
+            ok = a >= 0 and L.H5Awrite(a, L._native[key], v.ctypes.data_as(C.c_void_p)) >= 0
+            L.H5Aclose(a); L.H5Sclose(sp)
+        if not ok:
+            raise OSError("writing attribute %s failed" % name)
+
+    def set_global(self, name, val):
+        g = self.L.H5Gopen2(self.fid, b"/", 0)
+        try:
+            self._attr(g, name, val)
+        finally:
+            self.L.H5Gclose(g)
+
+    def set_attr(self, var, name, val):
+        self._attr(self.vars[var][0], name, val)
+
+    # -- dimensions and variables
+    def createDimension(self, name, size):
+        self.dims[name] = (0 if size is None else int(size), size is None, len(self.dims))
+
+    def createVariable(self, name, dtype, dims, fill_value=None, zlib=False, complevel=4, nrec=0):
+        """`nrec`: current length of the unlimited dimension (records about to be written)."""
+        L = self.L
+        key = np.dtype(dtype).kind + str(np.dtype(dtype).itemsize)
+        shape, maxs = [], []
+        for d in dims:
+            size, unl, _ = self.dims[d]
+            shape.append(nrec if unl else size)
+            maxs.append(UNLIMITED if unl else size)
+        nd = len(dims)
+        sp = L.H5Screate_simple(nd, (hsize_t * nd)(*shape), (hsize_t * nd)(*maxs))
+        dcpl = L.H5Pcreate(L._dcpl_class)
+        L.H5Pset_attr_creation_order(dcpl, 3)
+        unlimited = any(self.dims[d][1] for d in dims)
+        if unlimited or zlib:
+            # netCDF's default layout for (record, n): one record per chunk; long rows are cut (a chunk is one deflate unit)
+            chunk = [1 if self.dims[d][1] else max(1, min(self.dims[d][0], 1 << 20)) for d in dims]
+            if nd == 1 and unlimited:
+                chunk = [1024]
+            L.H5Pset_chunk(dcpl, nd, (hsize_t * nd)(*chunk))
+            if zlib:
+                L.H5Pset_shuffle(dcpl)
+                L.H5Pset_deflate(dcpl, int(complevel))
+        if fill_value is not None:
+            fv = np.asarray([fill_value], dtype=np.dtype(key))
+            L.H5Pset_fill_value(dcpl, L._native[key], fv.ctypes.data_as(C.c_void_p))
+        d = L.H5Dcreate2(self.fid, name.encode(), L._std[key], sp, 0, dcpl, 0)
+        L.H5Pclose(dcpl); L.H5Sclose(sp)
+        if d < 0:
+            raise OSError("H5Dcreate2(%s) failed" % name)
+        self.vars[name] = (d, key, tuple(dims))
+        if fill_value is not None:
+            self._attr(d, "_FillValue", np.asarray([fill_value], dtype=np.dtype(key)))
+        return name
+
+    def write(self, name, data):
+        d, key, dims = self.vars[name]
+        a = np.ascontiguousarray(data, dtype=np.dtype(key))
+        if self.L.H5Dwrite(d, self.L._native[key], 0, 0, 0, a.ctypes.data_as(C.c_void_p)) < 0:
+            raise OSError("H5Dwrite(%s) failed" % name)
+
+    def close(self):
+        """Turn the coordinate variables into dimension scales, attach every variable to its scales, close."""
+        if self.fid < 0:
+            return
+        L, H = self.L, self.H
+        for dname, (size, unl, dimid) in self.dims.items():
+            if dname not in self.vars:
+                raise ValueError("dimension %s needs its coordinate variable" % dname)
+            did = self.vars[dname][0]
+            if H.H5DSset_scale(did, dname.encode()) < 0:
+                raise OSError("H5DSset_scale(%s) failed" % dname)
+            self._attr(did, "_Netcdf4Dimid", np.int32(dimid))
+        for vname, (vid, key, dims) in self.vars.items():
+            if vname in self.dims:
+                continue
+            for k, dname in enumerate(dims):
+                if H.H5DSattach_scale(vid, self.vars[dname][0], k) < 0:
+                    raise OSError("H5DSattach_scale(%s, %s) failed" % (vname, dname))
+        for vid, _, _ in self.vars.values():
+            L.H5Dclose(vid)
+        L.H5Fclose(self.fid)
+        self.fid = -1

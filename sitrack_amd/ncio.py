@@ -5,10 +5,11 @@ Same function names, arguments and return values as the reference, same on-disk 
 si3_part_tracker.py:365-374 for the `icemod` records).  Two differences, both forced by
 the environment: (1) the geographic -> polar-stereographic conversion goes through
 libsitrk's projection kernel instead of cartopy; (2) the reference's hard dependency on the
-`netCDF4` package becomes optional: when it is absent, NetCDF-3 (classic / 64-bit offset)
-files are read and written with `scipy.io.netcdf_file`.  NetCDF-3 has no int64 and no
-compression, so in that fall-back `id_buoy` is stored as float64 (exact up to 2^53; buoy IDs
-reach 3e14) and `zlib` is dropped; everything else is identical.
+`netCDF4` package becomes optional: when it is absent, NetCDF-4 files are read AND written
+through the system's libhdf5 (h5lite.py: same variable types, `id_buoy` int64, shuffle +
+deflate 9, unlimited `time`, dimension scales -- a file `netCDF4`/`ncdump` read as NetCDF-4),
+classic NetCDF-3 inputs are read with `scipy.io.netcdf_file`.  Only where libhdf5 cannot be
+loaded either, outputs fall back to NetCDF-3 (no int64: `id_buoy` as float64; no compression).
 """
 import os
 from os import path
@@ -30,6 +31,8 @@ def backend():
     if _nc4 is not None:
         return "netCDF4"
     from . import h5lite
+    if h5lite.writer_available():
+        return "libhdf5 (NetCDF-4 read + write) + scipy (NetCDF-3 read)"
     return "scipy-netcdf3" + (" + libhdf5 reader" if h5lite.available() else "")
 
 
@@ -330,6 +333,10 @@ def ncSaveCloudBuoys(cf_out, ptime, pIDs, pY, pX, pLat, pLon, mask=[], xtime=[],
     os.makedirs(path.dirname(cf_out) or '.', exist_ok=True)
     about = 'Lagrangian sea-ice drift'
     author = 'Generated with `' + cauthor + '` of `sitrack` (L. Brodeau, 2023)'
+    from . import h5lite
+    if _nc4 is None and h5lite.writer_available():
+        return _save_nc4_hdf5(cf_out, ptime, pIDs, pY, pX, pLat, pLon, mask if lSaveMask else None, xtime if lSaveTime else None,
+                              tunits, fillVal, corigin, about, author)
     if _nc4 is not None:
         f = _nc4.Dataset(cf_out, 'w', format='NETCDF4')
         f.createDimension('time', None)
@@ -355,6 +362,9 @@ def ncSaveCloudBuoys(cf_out, ptime, pIDs, pY, pX, pLat, pLon, mask=[], xtime=[],
         v_buoy = f.createVariable('buoy', 'i4', ('buoy',))
         v_bid = f.createVariable('id_buoy', 'f8', ('buoy',))          # NetCDF-3 has no int64
         v_bid.note = 'int64 IDs stored as float64 (NetCDF-3 fall-back writer)'
+        if np.any(np.abs(np.asarray(pIDs, dtype=np.int64)) > 2 ** 53):
+            raise ValueError('ncSaveCloudBuoys: a buoy ID beyond 2^53 cannot be stored by the NetCDF-3 fall-back writer '
+                             '(float64 id_buoy); install netCDF4 or make libhdf5 + libhdf5_hl loadable')
         x_lat = f.createVariable('latitude', 'f4', ('time', 'buoy'))
         x_lon = f.createVariable('longitude', 'f4', ('time', 'buoy'))
         x_ykm = f.createVariable('y_pos', 'f4', ('time', 'buoy'))
@@ -391,4 +401,52 @@ def ncSaveCloudBuoys(cf_out, ptime, pIDs, pY, pX, pLat, pLon, mask=[], xtime=[],
     f.About = about
     f.Author = author
     f.close()
+    return 0
+
+
+def _save_nc4_hdf5(cf_out, ptime, pIDs, pY, pX, pLat, pLon, mask, xtime, tunits, fillVal, corigin, about, author):
+    """ncSaveCloudBuoys without the netCDF4 package: the same NetCDF-4 file (reference ncio.py:143-195 -- dimensions,
+    variable types, `_FillValue`, shuffle + deflate at level 9, units, global attributes) written through libhdf5."""
+    from . import h5lite
+    Nt, Nb = len(ptime), len(pIDs)
+    lvl = int(os.environ.get('SITRK_NC_COMPLEVEL', '9'))          # the reference's complevel; lower it for 10^7-buoy files
+    w = h5lite.NC4Writer(cf_out)
+    try:
+        w.createDimension('time', None)
+        w.createDimension('buoy', Nb)
+        w.createVariable('time', 'i4', ('time',), nrec=Nt)
+        w.createVariable('buoy', 'i4', ('buoy',))
+        w.createVariable('id_buoy', 'i8', ('buoy',))
+        kw = dict(fill_value=fillVal, zlib=True, complevel=lvl, nrec=Nt)
+        for name in ('latitude', 'longitude', 'y_pos', 'x_pos'):
+            w.createVariable(name, 'f4', ('time', 'buoy'), **kw)
+        if mask is not None:
+            w.createVariable('mask', 'i1', ('time', 'buoy'), zlib=True, complevel=lvl, nrec=Nt)
+        if xtime is not None:
+            w.createVariable('time_pos', 'i4', ('time', 'buoy'), **kw)
+        w.set_attr('time', 'units', tunits)
+        w.set_attr('id_buoy', 'units', 'ID of buoy')
+        w.set_attr('latitude', 'units', 'degrees north')
+        w.set_attr('longitude', 'units', 'degrees south')
+        w.set_attr('y_pos', 'units', 'km')
+        w.set_attr('x_pos', 'units', 'km')
+        if xtime is not None:
+            w.set_attr('time_pos', 'units', tunits)
+        w.write('buoy', np.arange(Nb, dtype='i4'))
+        w.write('id_buoy', np.asarray(pIDs, dtype=np.int64))
+        w.write('time', np.asarray(ptime).astype('i4'))
+        w.write('latitude', np.asarray(pLat, dtype=np.float32))
+        w.write('longitude', np.asarray(pLon, dtype=np.float32))
+        w.write('y_pos', np.asarray(pY, dtype=np.float32))
+        w.write('x_pos', np.asarray(pX, dtype=np.float32))
+        if mask is not None:
+            w.write('mask', np.asarray(mask, dtype='i1'))
+        if xtime is not None:
+            w.write('time_pos', np.asarray(xtime).astype('i4'))
+        if corigin:
+            w.set_global('Origin', corigin)
+        w.set_global('About', about)
+        w.set_global('Author', author)
+    finally:
+        w.close()
     return 0

@@ -140,6 +140,121 @@ def test_ncio_schema_and_roundtrip_both_backends(tmp_path, monkeypatch):
         assert made[v] == ('f4', ('time', 'buoy'), dict(fill_value=-9999., zlib=True, complevel=9))
 
 
+def _h5_header(fname):
+    """`h5dump -H -p` parsed into {object: {"type", "space", "filters", "fill", "attrs": {name: (type, space)}}}"""
+    import re
+    import shutil
+    import subprocess
+    exe = shutil.which("h5dump") or "/opt/conda/bin/h5dump"
+    if not os.path.exists(exe):
+        pytest.skip("no h5dump here")
+    txt = subprocess.run([exe, "-H", "-p", fname], capture_output=True, text=True, check=True).stdout
+    objs, cur, att, stack = {"/": {"attrs": {}}}, "/", None, []
+    lines = txt.splitlines()
+    k = 0
+
+    def block(k0):
+        """text of the {...} block opening on line k0 (one line or several), index of its last line"""
+        depth, out, k1 = 0, [], k0
+        while True:
+            out.append(lines[k1].strip())
+            depth += lines[k1].count("{") - lines[k1].count("}")
+            if depth <= 0:
+                return " ".join(out), k1
+            k1 += 1
+    while k < len(lines):
+        ln = lines[k].strip()
+        m = re.match(r'DATASET "(.*)" \{', ln)
+        if m:
+            cur, att = m.group(1), None
+            objs[cur] = {"attrs": {}}
+        m = re.match(r'ATTRIBUTE "(.*)" \{', ln)
+        if m:
+            att = m.group(1)
+            objs[cur]["attrs"][att] = [None, None]
+        if ln.startswith("DATATYPE"):
+            t, k = block(k)
+            t = re.sub(r"\s+", " ", t)
+            if att:
+                objs[cur]["attrs"][att][0] = t
+            else:
+                objs[cur]["type"] = t
+        elif ln.startswith("DATASPACE"):
+            if att:
+                objs[cur]["attrs"][att][1] = ln
+                att = None
+            else:
+                objs[cur]["space"] = ln
+        elif ln.startswith("FILTERS"):
+            t, k = block(k)
+            objs[cur]["filters"] = re.sub(r"\s+", " ", t)
+        elif ln.startswith("FILLVALUE"):
+            t, k = block(k)
+            objs[cur]["fill"] = re.sub(r"\s+", " ", t)
+        elif ln.startswith("STORAGE_LAYOUT"):
+            t, k = block(k)
+            objs[cur]["layout"] = "CHUNKED" if "CHUNKED" in t else "CONTIGUOUS"
+        k += 1
+    return objs
+
+
+def test_netcdf4_output_header_equals_the_reference_files(tmp_path, golden):
+    """The writer used when the `netCDF4` package is absent (libhdf5 + dimension scales) against the reference's own
+    committed NetCDF-4 file, tools/nc/sitrack_seeding_sidfex_19961215_00_HSS5.nc__KEEP (written by netCDF4-python through
+    `ncSaveCloudBuoys`, reference ncio.py:131-197): same content in, then `h5dump -H -p` variable for variable -- HDF5
+    type, dataspace incl. the unlimited `time`, chunked layout, shuffle + deflate 9, fill value, and every attribute's
+    type and shape (`id_buoy` is int64).  Allowed differences: netCDF-C's bookkeeping attributes `_NCProperties` /
+    `_Netcdf4Coordinates`, which readers do not need."""
+    from sitrack_amd import h5lite
+    if not h5lite.writer_available():
+        pytest.skip("libhdf5 / libhdf5_hl not loadable here")
+    ref = os.path.join(os.path.dirname(__file__), "golden", "sitrack_seeding_sidfex_19961215_00_HSS5.nc")
+    g = golden("g7_projection.npz")
+    f = str(tmp_path / "sitrack_seeding_sidfex_19961215_00_HSS5.nc")
+    import sitrack_amd.ncio as nio
+    saved = nio._nc4
+    nio._nc4 = None
+    try:
+        ncio.ncSaveCloudBuoys(f, g["time"].astype('i4'), g["id_buoy"], g["y_pos"][None], g["x_pos"][None], g["latitude"][None],
+                              g["longitude"][None], corigin='idealized_seeding', cauthor='generate_sidfex_seeding.py')
+    finally:
+        nio._nc4 = saved
+    assert h5lite.is_hdf5(f)
+    a, b = _h5_header(ref), _h5_header(f)
+    skip = {"_NCProperties", "_Netcdf4Coordinates"}
+    assert set(a) == set(b) == {"/", "buoy", "id_buoy", "latitude", "longitude", "time", "x_pos", "y_pos"}
+    for name in a:
+        for key in ("type", "space", "filters", "fill", "layout"):
+            if name == "time" and key == "fill":
+                continue                 # netCDF-C gives an unfilled int variable its default fill (-2147483647); every record is written here
+            if name in ("buoy", "id_buoy") and key in ("layout", "fill"):
+                continue                 # small fixed-size variables: contiguous either way; fill-time bookkeeping only
+            assert a[name].get(key) == b[name].get(key), (name, key, a[name].get(key), b[name].get(key))
+        ra = {k: v for k, v in a[name]["attrs"].items() if k not in skip}
+        rb = {k: v for k, v in b[name]["attrs"].items() if k not in skip}
+        assert ra == rb, (name, ra, rb)
+    assert "H5T_STD_I64LE" in b["id_buoy"]["type"] and "H5S_UNLIMITED" in b["latitude"]["space"]
+    assert "DEFLATE { LEVEL 9 }" in b["x_pos"]["filters"] and "SHUFFLE" in b["x_pos"]["filters"]
+    # and the data round-trip through the reader, next to the reference file's own
+    for src in (ref, f):
+        zt, ids, zg, zc = ncio.LoadNCdata(src, krec=0)
+        assert np.array_equal(ids, g["id_buoy"]) and ids.dtype == np.int64 and int(zt) == int(g["time"][0])
+        assert np.array_equal(zc[:, 0].astype('f4'), g["y_pos"]) and np.array_equal(zg[:, 0].astype('f4'), g["latitude"])
+    # IDs beyond 2^53 survive (they could not as the float64 of the NetCDF-3 fall-back)
+    big = np.array([2 ** 53 + 1, 2 ** 62 + 12345, 300534062025510], dtype=np.int64)
+    f2 = str(tmp_path / "a_b_c.nc")
+    nio._nc4 = None
+    try:
+        ncio.ncSaveCloudBuoys(f2, np.array([1, 2]), big, np.zeros((2, 3)), np.zeros((2, 3)), np.zeros((2, 3)), np.zeros((2, 3)),
+                              mask=np.ones((2, 3), dtype='i1'), xtime=np.ones((2, 3), dtype=int))
+    finally:
+        nio._nc4 = saved
+    assert np.array_equal(ncio.LoadNCdata(f2, krec=-1)[1], big)
+    hdr = _h5_header(f2)
+    assert "DEFLATE { LEVEL 9 }" in hdr["mask"]["filters"] and "H5T_STD_I8LE" in hdr["mask"]["type"] and "_FillValue" not in hdr["mask"]["attrs"]
+    assert "H5T_STD_I32LE" in hdr["time_pos"]["type"] and "_FillValue" in hdr["time_pos"]["attrs"]
+
+
 def _write_nc3(fname, dims, variables, attrs=None):
     from scipy.io import netcdf_file
     f = netcdf_file(fname, 'w', version=2)
