@@ -206,6 +206,17 @@ int sitrk_seed_init(sitrk_t *h, int64_t nP, const double *latlon, const double *
 int sitrk_nearest_point(sitrk_t *h, int64_t nP, const double *latlon, const double *latT, const double *lonT,
                         const double *resolkm, double rd_found_km, int max_itr, int32_t *ji, double *dmin);
 
+/* Idealised seeding on the model grid: nemoSeed (sitrack/tracking.py:365-442) + Geo2CartNPSkm1D (util.py:394-410), i.e. what
+ * tools/generate_idealized_seeding.py computes (:201-386), on the device.  Every khss-th T-point of the (Nj,Ni) mesh
+ * whose tmask x rmask (rmask may be NULL) is 1, whose latitude is not below 55 and whose ice concentration is not below
+ * 0.9 carries a seed; with latF/lonF (both or neither) also every interior sub-sampled F-point whose four sub-sampled
+ * T-neighbours carry one.  Outputs in the reference's order -- T-seeds in C order of the sub-sampled mesh, then F-seeds
+ * -- as latlon (n,2) [lat,lon] and, if yx != NULL, yx (n,2) [y,x] km in the polar-stereographic plane (lat0, lon0).
+ * Call once with capacity = 0 to learn the counts (*nT, *nF), then with arrays of nT + nF rows. */
+int sitrk_nemo_seed(sitrk_t *h, int Nj, int Ni, int khss, const int8_t *tmask, const int8_t *rmask,
+                    const double *latT, const double *lonT, const double *sic, const double *latF, const double *lonF,
+                    double lat0, double lon0, int64_t capacity, double *latlon, double *yx, int64_t *nT, int64_t *nF);
+
 /* ---- predicate probes ------------------------------------------------------
  * The device-side predicates of the hot path evaluated on plain arrays, so that each one can be held
  * against the reference function it restates (parity tests):

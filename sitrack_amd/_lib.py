@@ -55,6 +55,7 @@ _SIGNATURES = {
     "sitrk_count_alive": (_int, [_vp, C.POINTER(_i64)]),
     "sitrk_find_cells": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "sitrk_seed_init": (_int, [_vp, _i64] + [_vp] * 9),
+    "sitrk_nemo_seed": (_int, [_vp, _int, _int, _int] + [_vp] * 7 + [_dbl, _dbl, _i64, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "sitrk_nearest_point": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _dbl, _int, _vp, _vp]),
     "sitrk_eval_haversine": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "sitrk_eval_inside": (_int, [_vp, _i64, _vp, _vp, _vp]),
@@ -367,6 +368,25 @@ class Context:
         self._chk(self._L.sitrk_seed_init(self._h, nP, _ptr(latlon), _ptr(yx), _ptr(latT), _ptr(lonT), _ptr(res), _ptr(sic),
                                           _ptr(jiT), _ptr(keep), _ptr(why)))
         return jiT, keep, why
+
+    def nemo_seed(self, tmask, latT, lonT, sic, khss=1, rmask=None, latF=None, lonF=None, lat0=70., lon0=-45.):
+        """sitrk_nemo_seed: (latlon (n,2), yx (n,2) km, nT, nF) -- T-seeds first, then F-seeds, each in C order."""
+        tm = as_c(tmask, np.int8)
+        Nj, Ni = tm.shape
+        shp = (Nj, Ni)
+        la, lo, ic = (as_c(x, np.float64, shp, n) for x, n in ((latT, "latT"), (lonT, "lonT"), (sic, "sic")))
+        rm = None if rmask is None else as_c(rmask, np.int8, shp, "rmask")
+        lf = None if latF is None else as_c(latF, np.float64, shp, "latF")
+        of = None if lonF is None else as_c(lonF, np.float64, shp, "lonF")
+        nT, nF = _i64(0), _i64(0)
+        args = (self._h, Nj, Ni, int(khss), _ptr(tm), _ptr(rm), _ptr(la), _ptr(lo), _ptr(ic), _ptr(lf), _ptr(of), float(lat0), float(lon0))
+        self._chk(self._L.sitrk_nemo_seed(*args, 0, None, None, C.byref(nT), C.byref(nF)))
+        n = nT.value + nF.value
+        ll = np.empty((n, 2), dtype=np.float64)
+        yx = np.empty((n, 2), dtype=np.float64)
+        if n:
+            self._chk(self._L.sitrk_nemo_seed(*args, n, _ptr(ll), _ptr(yx), C.byref(nT), C.byref(nF)))
+        return ll, yx, nT.value, nF.value
 
     def nearest_point(self, latlon, latT, lonT, resolkm=None, rd_found_km=10., max_itr=5):
         """NearestPoint of the reference for an array of points: (ji (n,2) int32 with -1,-1 = not found, dmin km)."""

@@ -14,6 +14,7 @@
 #include "sitrk_internal.h"
 #include "sitrk_kernels.h"
 #include "sitrk_locate.h"
+#include "sitrk_seed.h"
 
 using namespace sitrk;
 
@@ -1244,6 +1245,74 @@ SITRK_API int sitrk_cart2geo(sitrk_t *h, int64_t n, const double *yx, double lat
 SITRK_API int sitrk_geo2cart(sitrk_t *h, int64_t n, const double *latlon, double lat0, double lon0, double *yx)
 {
     return project(h, n, latlon, lat0, lon0, yx, false);
+}
+
+// --------------------------------------------------------------------------- idealised seeding
+SITRK_API int sitrk_nemo_seed(sitrk_t *h, int Nj, int Ni, int khss, const int8_t *tmask, const int8_t *rmask, const double *latT,
+                              const double *lonT, const double *sic, const double *latF, const double *lonF, double lat0, double lon0,
+                              int64_t capacity, double *latlon, double *yx, int64_t *nT, int64_t *nF)
+{
+    NEED(h, "null handle");
+    NEED(Nj >= 1 && Ni >= 1 && (int64_t)Nj * Ni < ((int64_t)1 << 31), "sitrk_nemo_seed: bad mesh shape");
+    NEED(khss >= 1, "sitrk_nemo_seed: khss must be >= 1");
+    NEED(tmask && latT && lonT && sic, "sitrk_nemo_seed: null array");
+    NEED((latF == nullptr) == (lonF == nullptr), "sitrk_nemo_seed: latF and lonF go together");
+    NEED(nT && nF, "sitrk_nemo_seed: null count output");
+    NEED(capacity >= 0 && (capacity == 0 || latlon), "sitrk_nemo_seed: capacity without an output array");
+    HIPCHK(hipSetDevice(h->device));
+    SeedArgs s;
+    s.Nj = Nj; s.Ni = Ni; s.khss = khss;
+    s.Njs = (Nj + khss - 1) / khss; s.Nis = (Ni + khss - 1) / khss;        // shape of array[::khss, ::khss]
+    s.with_f = latF ? 1 : 0;
+    const size_t n = (size_t)Nj * Ni;
+    const int64_t ns = (int64_t)s.Njs * s.Nis, nblk_t = (ns + kSeedBlock - 1) / kSeedBlock, nblk = 2 * nblk_t;
+    const size_t b_d = align256(n * 8), b_m = align256(n), b_c = align256((size_t)nblk * 4), b_o = align256((size_t)nblk * 8),
+                 b_out = align256((size_t)capacity * 16);
+    int rc = ensure_scratch(h, 5 * b_d + 2 * b_m + b_c + b_o + 256 + 2 * b_out);
+    if (rc) return rc;
+    char *w = (char *)h->scratch;
+    double *d_latT = (double *)w;           w += b_d;
+    double *d_lonT = (double *)w;           w += b_d;
+    double *d_sic = (double *)w;            w += b_d;
+    double *d_latF = (double *)w;           w += b_d;
+    double *d_lonF = (double *)w;           w += b_d;
+    int8_t *d_tm = (int8_t *)w;             w += b_m;
+    int8_t *d_rm = (int8_t *)w;             w += b_m;
+    unsigned *d_cnt = (unsigned *)w;        w += b_c;
+    int64_t *d_off = (int64_t *)w;          w += b_o;
+    int64_t *d_tot = (int64_t *)w;          w += 256;
+    ll *d_ll = (ll *)w;                     w += b_out;
+    pt *d_yx = (pt *)w;
+    HIPCHK(hipMemcpyAsync(d_latT, latT, n * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_lonT, lonT, n * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_sic, sic, n * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_tm, tmask, n, hipMemcpyHostToDevice, h->stream));
+    if (rmask) HIPCHK(hipMemcpyAsync(d_rm, rmask, n, hipMemcpyHostToDevice, h->stream));
+    if (latF) {
+        HIPCHK(hipMemcpyAsync(d_latF, latF, n * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(d_lonF, lonF, n * 8, hipMemcpyHostToDevice, h->stream));
+    }
+    s.tmask = d_tm; s.rmask = rmask ? d_rm : nullptr;
+    s.latT = d_latT; s.lonT = d_lonT; s.sic = d_sic; s.latF = d_latF; s.lonF = d_lonF;
+    hipLaunchKernelGGL(seed_count_kernel, dim3((unsigned)nblk), dim3(kSeedBlock), 0, h->stream, s, nblk_t, d_cnt);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(seed_scan_kernel, dim3(1), dim3(kSeedBlock), 0, h->stream, nblk, nblk_t, d_cnt, d_off, d_tot);
+    HIPCHK(hipGetLastError());
+    int64_t tot[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *nT = tot[0]; *nF = tot[1];
+    if (capacity == 0) return SITRK_OK;                 // counting call
+    if (capacity < tot[0] + tot[1])
+        return fail(h, SITRK_EINVAL, "sitrk_nemo_seed: %lld seeds do not fit the capacity %lld", (long long)(tot[0] + tot[1]), (long long)capacity);
+    hipLaunchKernelGGL(seed_emit_kernel, dim3((unsigned)nblk), dim3(kSeedBlock), 0, h->stream, s, nblk_t, d_off, make_proj(lat0, lon0), capacity,
+                       d_ll, yx ? d_yx : nullptr);
+    HIPCHK(hipGetLastError());
+    const size_t nout = (size_t)(tot[0] + tot[1]);
+    HIPCHK(hipMemcpyAsync(latlon, d_ll, nout * 16, hipMemcpyDeviceToHost, h->stream));
+    if (yx) HIPCHK(hipMemcpyAsync(yx, d_yx, nout * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SITRK_OK;
 }
 
 // --------------------------------------------------------------------------- measurement

@@ -149,8 +149,23 @@ def _record_windows_loop(zTpos, tm, z1st, zLst, late, early, half):
     return z1st, zLst
 
 
+class _Clock:
+    """wall-clock shares of a run (where the command line spends its time: reading, the GPU, writing)"""
+
+    def __init__(self):
+        import time
+        self.now = time.perf_counter
+        self.t = {}
+        self.t0 = self.now()
+
+    def add(self, key, since):
+        self.t[key] = self.t.get(key, 0.0) + (self.now() - since)
+        return self.now()
+
+
 def main(argv=None):
     a = parse_args(argv)
+    clk = _Clock()
     cf_uv, cf_mm, fNCseed, jrecSeed, cdate_stop, CONF = a.fsi3, a.fmmm, a.fsdg, a.krec, a.dend, a.ncnf
     lUse2DTime = not a.fxdt
     iUVstrategy = a.uv_strategy
@@ -180,6 +195,7 @@ def main(argv=None):
             os.makedirs(cd, exist_ok=True)
 
     ctx = _lib.Context(a.device if comm.world == 1 else comm.device)
+    tk = clk.now()
     imaskt, xlatT, xlonT, xYt, xXt, xYf, xXf, xResKM = ncio.GetModelGrid(cf_mm, ctx=ctx)
     if iUVstrategy >= 1:
         xYv, xXv, xYu, xXu = ncio.GetModelUVGrid(cf_mm, ctx=ctx)
@@ -187,6 +203,7 @@ def main(argv=None):
         xYv, xXv, xYu, xXu = xYf, xXf, xYf, xXf     # never read by the cell-mean rule
     (Nj, Ni) = np.shape(imaskt)
     records = ncio.ModelRecords(cf_uv)
+    tk = clk.add("read_mesh_s", tk)
 
     # ---- seeding, with the reference's intermediate cache (:205-255).  Seeds are independent: with several ranks
     #      each one locates its own contiguous range and the results are concatenated in rank (= seed) order.
@@ -215,6 +232,7 @@ def main(argv=None):
         if comm.root:
             _savez_deflate(cf_npz_itm, nP=nP, xPosG0=xPosG0, xPosC0=xPosC0, IDs=IDs, vJIt=vJIt, VRTCS=VRTCS, idxKeep=idxK)
 
+    tk = clk.add("seed_init_and_cache_s", tk)
     # ---- per-buoy record windows (:264-318)
     z1stModelRec = np.zeros(nP, dtype=int) + kstrt
     zLstModelRec = np.zeros(nP, dtype=int) + kstop
@@ -291,6 +309,7 @@ def main(argv=None):
 
     def upload(jt0, m):
         """records jt0..jt0+m-1 -> slots (jt0+r) % K, asynchronously"""
+        t_up = clk.now()
         if not a.full_records:
             # rows this rank's buoys can touch during those records: the host rows at the last evaluation, widened by one
             # row per record stepped or queued since (sitrk_buoy_rows waits for the GPU: only every so often)
@@ -313,7 +332,10 @@ def main(argv=None):
                 ctx.submit(slot, 0)
             else:
                 comm.deliver_record(ctx, slot, records.fields(jrec) if comm.root else None)   # rank 0 reads, RCCL broadcast
+        clk.add("read_and_stage_records_s", t_up)
 
+    tk = clk.add("setup_s", tk)
+    t_loop = clk.now()
     if batches:
         upload(*batches[0])
     for ib, (jt0, m) in enumerate(batches):
@@ -326,11 +348,14 @@ def main(argv=None):
         else:
             say(' *** records #%d..#%d/%d  dates = %s .. %s   (one fused launch)' % (jrec0 + 1, jrecN + 1, Nt0, epoch2clock(vTime[jt0]),
                                                                                    epoch2clock(vTime[jt0 + m - 1])))
+        t_q = clk.now()
         trk.run(jrec0, jt0 % K, m)
+        clk.add("enqueue_stepping_s", t_q)
         if ib + 1 < len(batches):
             upload(*batches[ib + 1])               # travels while the launch above runs
         jt, jrec, itime = jt0 + m - 1, jrecN, vTime[jt0 + m - 1]
         need = need_output(jrec)
+        t_f = clk.now()
         if need:
             pos_l, msk_l = trk.record(jrec)
             pos, msk = to_caller_order(comm.gather_rows(pos_l, nP)), to_caller_order(comm.gather_rows(msk_l, nP))
@@ -346,7 +371,12 @@ def main(argv=None):
                 z2GC[1, sel] = ctx.cart2geo(pos[sel])
                 zMSK[1, sel] = msk[sel]
                 zTim[1, sel[stepped[sel]]] = int(itime + rdt)
+        clk.add("fetch_and_store_outputs_s", t_f)
+    ctx.sync()
+    clk.add("record_loop_s", t_loop)
+    tk = clk.now()
     records.close()
+    launches = ctx.launch_stats()
     vTime[Nt] = vTime[Nt - 1] + int(rdt)
     state = trk.state()
     vJIt_end, alive_end = to_caller_order(comm.gather_rows(state["vJIt"], nP)), to_caller_order(comm.gather_rows(state["iAlive"], nP))
@@ -382,5 +412,8 @@ def main(argv=None):
     print(' *** first and final dates in simulated trajectories:', epoch2clock(zvt[0]), epoch2clock(zvt[1]))
     for f in outs:
         print('      ===> ' + f + ' saved!')
+    clk.add("write_outputs_s", tk)
+    clk.t["total_s"] = clk.now() - clk.t0
     comm.close()
-    return {"files": outs, "nP": nP, "IDs": IDs, "vJIt": vJIt_end, "iAlive": alive_end, "Nt": Nt, "kstrt": kstrt}
+    return {"files": outs, "nP": nP, "IDs": IDs, "vJIt": vJIt_end, "iAlive": alive_end, "Nt": Nt, "kstrt": kstrt,
+            "timing": dict(clk.t), "launches": launches}

@@ -1,40 +1,31 @@
-"""Idealised seeding on the model grid -- vectorised mirror of reference `nemoSeed`
-(sitrack/tracking.py:365-442), used by tools/generate_idealized_seeding.py.  Host-side numpy
-(the reference fills its output in a Python loop over the kept points); the forward projection
-of the seeds goes through libsitrk (`Geo2CartNPSkm1D`)."""
+"""Idealised seeding on the model grid -- the surface of the reference's seeding generators (`nemoSeed`, `SidfexSeeding`,
+`ReadFromSidfexDatFile`; sitrack/tracking.py:331-442) as used by tools/generate_idealized_seeding.py.
+
+`nemoSeed` runs on the GPU (`sitrk_nemo_seed`, sitrack_amd/csrc/sitrk_seed.h): the decision which points of the sub-sampled
+mesh carry a seed, their compaction in the reference's output order and their projection to the polar-stereographic plane
+happen in three kernels; only the mesh arrays go in and the seed list comes out.  There is no host version."""
 import numpy as np
 
 
-def nemoSeed(pmskT, platT, plonT, pIC, khss=1, fmsk_rstrct=[], platF=[], plonF=[]):
-    """Every `khss`-th T-point north of 55N with ice concentration >= 0.9 inside the (optional)
-    restriction mask, in C order; optionally followed by the F-points whose four neighbouring
-    (sub-sampled) T-points are all kept.  Returns (n,2) [lat,lon]."""
-    lAddF = (np.shape(platF) == np.shape(pmskT) and np.shape(plonF) == np.shape(pmskT))
-    zmsk = pmskT[::khss, ::khss]
-    zlat = platT[::khss, ::khss]
-    zlon = plonT[::khss, ::khss]
-    (Nj, Ni) = np.shape(zmsk)
-    msk_T = np.zeros((Nj, Ni), dtype='i1')
-    msk_T[:, :] = zmsk[:, :]
-    if np.shape(fmsk_rstrct) == np.shape(pmskT):
-        maskR = fmsk_rstrct[::khss, ::khss]
-        if np.shape(maskR) != (Nj, Ni):
-            raise ValueError('ERROR [nemoSeed()]: restricted area mask does not agree in shape with model output!')
-        msk_T[:, :] = msk_T[:, :] * maskR[:, :]
-    msk_T[zlat < 55.] = 0                                   # only north of 55N (:406)
-    ztmp = np.zeros((Nj, Ni))
-    ztmp[:, :] = pIC[::khss, ::khss]
-    msk_T[ztmp < 0.9] = 0                                   # only over a decent concentration of ice (:411-412)
-    keep = msk_T == 1
-    zLatLon = np.stack([zlat[keep], zlon[keep]], axis=1).astype(np.float64)
-    if lAddF:
-        zlatF = platF[::khss, ::khss]
-        zlonF = plonF[::khss, ::khss]
-        msk_F = np.zeros(np.shape(msk_T), dtype='i1')
-        msk_F[1:-1, 1:-1] = (msk_T[2:, 1:-1] + msk_T[1:-1, 2:] + msk_T[:-2, 1:-1] + msk_T[1:-1, :-2]) / 4
-        keepF = msk_F == 1
-        zLatLon = np.concatenate([zLatLon, np.stack([zlatF[keepF], zlonF[keepF]], axis=1).astype(np.float64)])
-    return zLatLon
+def _same_shape(a, ref):
+    return np.shape(a) == np.shape(ref)
+
+
+def nemoSeed(pmskT, platT, plonT, pIC, khss=1, fmsk_rstrct=[], platF=[], plonF=[], ctx=None, return_yx=False):
+    """Seeds on every `khss`-th T-point (reference tracking.py:365-442, same arguments): where the land-sea mask --
+    times the optional restriction mask `fmsk_rstrct` -- is 1, north of 55N, under an ice concentration of at least 0.9.
+    When F-point coordinates of the mesh's shape are passed, F-points whose four sub-sampled T-neighbours all carry a
+    seed are appended.  Returns the (n,2) [lat,lon] array in the reference's order; with `return_yx` also their (n,2)
+    [y,x] km in the polar-stereographic plane (what the seeding tool computes next, util.py:394-410)."""
+    from .tracking import default_context
+    restricted = _same_shape(fmsk_rstrct, pmskT)
+    with_f = _same_shape(platF, pmskT) and _same_shape(plonF, pmskT)
+    if not (_same_shape(platT, pmskT) and _same_shape(plonT, pmskT) and _same_shape(pIC, pmskT)):
+        raise ValueError('ERROR [nemoSeed()]: mask, coordinates and ice concentration must share one shape')
+    latlon, yx, _, _ = (ctx or default_context()).nemo_seed(
+        pmskT, platT, plonT, pIC, khss=khss, rmask=fmsk_rstrct if restricted else None,
+        latF=platF if with_f else None, lonF=plonF if with_f else None)
+    return (latlon, yx) if return_yx else latlon
 
 
 def ReadFromSidfexDatFile(filepath='./sidfexloc.dat'):

@@ -106,6 +106,8 @@ def big(a):
         "case": "synthetic %dx%d mesh (%.1f km), %d seeds -> %d buoys kept, %d hourly records, 2-D-time mode (first/last written)"
                 % (a.nj, a.ni, a.dkm, a.buoys, nP, a.records),
         "cli_wall_s": t_cli, "particle_steps_upper_bound": psteps, "alive_at_end": int((out["iAlive"] == 1).sum()),
+        "where_the_time_goes_s": {k: round(v, 3) for k, v in out["timing"].items()},
+        "launches": out["launches"],
         "subsample_checked_against_oracle": int(len(sub)), "files": [os.path.basename(f) for f in out["files"]]}))
 
 

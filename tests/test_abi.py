@@ -162,13 +162,39 @@ def test_vertices_are_a_function_of_the_cell(golden):
     assert np.array_equal(sit.vertices_of(g["ojiT"]), g["overt"])
 
 
+@pytest.mark.gpu
 def test_nemoseed_matches_reference_golden(golden):
+    """G10 (made by the reference's own nemoSeed) through the C ABI on the GPU: which seeds, in which order -- bit for bit --
+    plus the fused projection against the projection entry point; sub-sampling that does not divide the mesh, the
+    restriction mask, F-points, NaN inputs and non-0/1 mask values like numpy treats them."""
     from sitrack_amd.seeding import nemoSeed
     g = golden("g10_nemoseed.npz")
     cases = {"a": dict(khss=1), "b": dict(khss=3), "c": dict(khss=2, fmsk_rstrct=g["rmask"]),
              "d": dict(khss=1, platF=g["latF"], plonF=g["lonF"]),
              "e": dict(khss=4, fmsk_rstrct=g["rmask"], platF=g["latF"], plonF=g["lonF"])}
-    for tag, kw in cases.items():
-        got = nemoSeed(g["tmask"], g["lat"], g["lon"], g["sic"], **kw)
-        assert np.array_equal(got, g["seed_" + tag]), tag
-        assert len(got) > 0
+    ctx = sit.Context(0)
+    try:
+        for tag, kw in cases.items():
+            got, yx = nemoSeed(g["tmask"], g["lat"], g["lon"], g["sic"], ctx=ctx, return_yx=True, **kw)
+            assert np.array_equal(got, g["seed_" + tag]), tag
+            assert len(got) > 0 and np.array_equal(yx, ctx.geo2cart(got))
+        # what numpy does with odd inputs: a NaN latitude / concentration does not satisfy `<`, so the point stays;
+        # mask values other than 0/1 only seed where the product is exactly 1; F-points need 4 <= sum < 8
+        rng = np.random.default_rng(3)
+        Nj, Ni = 29, 23
+        lat = 50. + 40. * rng.random((Nj, Ni)); lon = 360. * rng.random((Nj, Ni))
+        sic = rng.choice([0.5, 0.95, np.nan], size=(Nj, Ni)); lat[rng.random((Nj, Ni)) < 0.1] = np.nan
+        tm = rng.choice([0, 1, 1, 1, 2], size=(Nj, Ni)).astype('i1'); rm = rng.choice([0, 1, 1, -1], size=(Nj, Ni)).astype('i1')
+        for khss in (1, 2, 5):
+            m = (tm[::khss, ::khss] * rm[::khss, ::khss]).astype('i1')
+            with np.errstate(invalid='ignore'):
+                m[lat[::khss, ::khss] < 55.] = 0
+                m[sic[::khss, ::khss] < 0.9] = 0
+            wantT = np.stack([lat[::khss, ::khss][m == 1], lon[::khss, ::khss][m == 1]], axis=1)
+            mf = np.zeros_like(m)
+            mf[1:-1, 1:-1] = (m[2:, 1:-1] + m[1:-1, 2:] + m[:-2, 1:-1] + m[1:-1, :-2]) / 4
+            wantF = np.stack([(lat + 0.01)[::khss, ::khss][mf == 1], (lon + 0.02)[::khss, ::khss][mf == 1]], axis=1)
+            ll, yx, nT, nF = ctx.nemo_seed(tm, lat, lon, sic, khss=khss, rmask=rm, latF=lat + 0.01, lonF=lon + 0.02)
+            assert (nT, nF) == (len(wantT), len(wantF)) and np.array_equal(ll, np.concatenate([wantT, wantF]), equal_nan=True)
+    finally:
+        ctx.close()

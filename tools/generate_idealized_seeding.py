@@ -58,15 +58,17 @@ def main(argv=None):
             FSmask = np.array(f.var('tmask'), dtype='i1')
         if np.shape(FSmask) != np.shape(imaskt):
             raise SystemExit('ERROR: `shape(FSmask) != shape(imaskt)`')
-    XseedGC = nemoSeed(imaskt, xlatT, xlonT, xIC, khss=a.ihss, fmsk_rstrct=FSmask)
+    # which points carry a seed, their order and their projection: one call into the library (sitrk_nemo_seed)
+    XseedGC, XseedYX = nemoSeed(imaskt, xlatT, xlonT, xIC, khss=a.ihss, fmsk_rstrct=FSmask, ctx=ctx, return_yx=True)
     zIDs = np.arange(1, XseedGC.shape[0] + 1, dtype=int)
-    return write_seeding(ctx, a, seeding_type, XseedGC, zIDs)
+    return write_seeding(ctx, a, seeding_type, XseedGC, zIDs, XseedYX)
 
 
-def write_seeding(ctx, a, seeding_type, XseedGC, zIDs):
+def write_seeding(ctx, a, seeding_type, XseedGC, zIDs, XseedYX=None):
     nP = XseedGC.shape[0]
     t0 = driver.clock2epoch(a.dat0)
-    XseedYX = sit.Geo2CartNPSkm1D(XseedGC, ctx=ctx)
+    if XseedYX is None:
+        XseedYX = sit.Geo2CartNPSkm1D(XseedGC, ctx=ctx)
     cdate = datetime.fromtimestamp(t0, timezone.utc).strftime("%Y%m%d_%H")
     cextra = '_HSS' + str(a.ihss) if a.ihss > 1 else ''
     foutnc = './nc/sitrack_seeding_' + seeding_type + '_' + cdate + cextra + '.nc'
