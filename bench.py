@@ -257,7 +257,13 @@ def main():
     dist = None
     backend = os.environ.get("SITRK_DIST_BACKEND", "nccl")
     dev = int(os.environ.get("SITRK_DEVICE", str(local_rank)))
-    if world > 1:
+    force = world == 1 and os.environ.get("SITRK_FORCE_DIST") == "1"      # rehearsal of the N > 1 code path with one RCCL rank
+    if force:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force:
         import torch.distributed as dist
         torch.cuda.set_device(dev)
         import datetime
@@ -302,11 +308,11 @@ def main():
     if rank == 0:
         u, v, sic = syn.make_fields(grid, K=K, seed=2024, umax=0.3, drift=0.05)
         slabs_host = [sd.pack_slab(u[k], v[k], sic[k], np.float32) for k in range(K)]
-    records_via = "host upload" if world == 1 else ("RCCL broadcast from rank 0" if backend == "nccl" else backend + " broadcast from rank 0")
+    records_via = "host upload" if dist is None else ("RCCL broadcast from rank 0" if backend == "nccl" else backend + " broadcast from rank 0")
     if a.regime == "resident":
         try:
             for k in range(K):
-                if world > 1 and backend == "nccl":
+                if dist is not None and backend == "nccl":
                     sd.broadcast_record(ctx, k, slabs_host[k] if rank == 0 else None, src=0)
                 elif world > 1:
                     slab = sd.broadcast_record_host(slabs_host[k] if rank == 0 else None, ctx.slab_elems, np.float32, src=0)
@@ -314,7 +320,7 @@ def main():
                 else:
                     ctx.push_record(k, u[k], v[k], sic[k])
         except Exception as e:                          # noqa: BLE001 -- keep the scaling run alive: the records are deterministic
-            if world == 1:
+            if dist is None or force:
                 raise
             print("rank %d: record broadcast failed (%r); generating the records locally" % (rank, e), file=sys.stderr)
             records_via = "generated on every rank (broadcast failed: %s)" % type(e).__name__

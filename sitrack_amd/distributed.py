@@ -119,20 +119,94 @@ def broadcast_record_host(slab_host, nelem, dtype, src=0, group=None):
 
 
 def gather_ranges(local, nP, group=None, dst=0):
-    """Gather per-rank arrays (first axis = the rank's buoy range) back into caller order on `dst`.
+    """Gather per-rank arrays (first axis = the rank's buoy range of `nP`, buoy_range()) back into buoy order on `dst`.
 
-    Works with any backend (objects are small compared with the trajectories' size on the
-    path that uses it: the end-of-run fetch)."""
+    A TENSOR gather: every rank's rows travel as one contiguous buffer (padded to the longest range; the ranges are a
+    function of (nP, world) alone, so no sizes are exchanged) -- through RCCL as device tensors with backend nccl,
+    through gloo as host tensors.  At C4 a gathered record is 1.6 GB of positions; as pickled objects
+    (`gather_object`) it would be serialised on every rank and deserialised on rank 0."""
+    import torch
     import torch.distributed as dist
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    parts = [None] * world if rank == dst else None
-    dist.gather_object(local, parts, dst=dst, group=group)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    ranges = all_ranges(nP, world)
+    lo, hi = ranges[rank]
+    a = np.ascontiguousarray(local)
+    if a.shape[0] != hi - lo:
+        raise ValueError("gather_ranges: rank %d holds %d rows, its range of %d buoys has %d" % (rank, a.shape[0], nP, hi - lo))
+    nmax = max(h - l for l, h in ranges)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.zeros((nmax,) + a.shape[1:], dtype=torch.from_numpy(a[:0]).dtype, device=dev)
+    if hi > lo:
+        t[:hi - lo].copy_(torch.from_numpy(a))
+    bufs = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
+    dist.gather(t, bufs, dst=dst, group=group)
     if rank != dst:
         return None
-    out = np.concatenate(parts, axis=0)
-    assert out.shape[0] == nP
+    out = np.empty((nP,) + a.shape[1:], dtype=a.dtype)
+    for r, (l, h) in enumerate(ranges):
+        if h > l:
+            out[l:h] = bufs[r][:h - l].cpu().numpy()
     return out
+
+
+class RecordBroadcaster:
+    """Delivery of whole records to every rank, overlapped with the stepping (driver `--full-records` under torchrun,
+    SURVEY 8e): rank 0 copies the record from pinned host memory into its resident slot on a communication stream,
+    ONE broadcast of the [u|v|siconc] slab (RCCL over xGMI) writes every other rank's slot in place, and the compute
+    stream -- the library's, adopted from torch for the ordering -- only waits for the slot's event before it derives the
+    record's Survive mask and steps.  A slot is rewritten only behind the launches that read it.  `deliver()` returns at
+    once; the records of the next batch travel while the current batch is stepped with."""
+
+    def __init__(self, ctx, src=0, group=None):
+        import torch
+        import torch.distributed as dist
+        self.ctx, self.src, self.group, self.dist, self.torch = ctx, src, group, dist, torch
+        self.rank = dist.get_rank(group)
+        self.comp, self.comm = torch.cuda.Stream(), torch.cuda.Stream()
+        ctx.set_stream(self.comp.cuda_stream)
+        self.slots = [slot_tensor(ctx, k) for k in range(ctx.nslots)]
+        self.ready = [torch.cuda.Event() for _ in range(ctx.nslots)]
+        self.free = [torch.cuda.Event() for _ in range(ctx.nslots)]
+        self.pinned = [None, None]                       # two staging buffers on the source rank
+        self.pin_done = [torch.cuda.Event(), torch.cuda.Event()]
+        self.npush = 0
+        for e in self.free:
+            e.record(self.comp)
+
+    def deliver(self, slot, fields):
+        """`fields` = (u, v, sic) on the source rank, None elsewhere"""
+        torch = self.torch
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(self.free[slot])        # the launches that read the slot have finished
+            if self.rank == self.src:
+                b = self.npush % 2
+                if self.pinned[b] is None:
+                    self.pinned[b] = torch.empty(self.ctx.slab_elems, dtype=self.slots[slot].dtype).pin_memory()
+                self.pin_done[b].synchronize()           # the copy that last read this staging buffer is done
+                n = self.ctx.Nj * self.ctx.Ni
+                host = self.pinned[b].numpy()
+                for f, a in enumerate(fields):
+                    host[f * n:(f + 1) * n] = np.asarray(a).reshape(-1)
+                self.slots[slot].copy_(self.pinned[b], non_blocking=True)
+                self.pin_done[b].record(self.comm)
+                self.npush += 1
+            self.dist.broadcast(self.slots[slot], src=self.src, group=self.group)
+            self.ready[slot].record(self.comm)
+        self.ctx.record_ptr(slot)                        # the slab was rewritten in place: its mask must be derived again
+
+    def before_run(self, slots):
+        """order the compute stream behind the deliveries of `slots` and derive their Survive masks"""
+        for k in slots:
+            self.comp.wait_event(self.ready[k])
+            self.ctx.commit_record(k)
+
+    def after_run(self, slots):
+        for k in slots:
+            self.free[k].record(self.comp)
+
+    def close(self):
+        self.comp.synchronize(); self.comm.synchronize()
+        self.ctx.set_stream(None)
 
 
 def split_slab(slab, Nj, Ni):
@@ -193,6 +267,44 @@ class Comm:
         if self.world == 1:
             return int(n)
         return int(sum(self.allgather_obj(int(n))))
+
+    def _dev(self):
+        return "cuda" if self.backend == "nccl" else "cpu"
+
+    def allgather_rows(self, arrays):
+        """Every rank contributes a tuple of arrays with one common (rank-dependent) number of rows; every rank gets back
+        the tuple of their concatenations in rank order.  Tensor collectives (sizes first, then one padded all-gather per
+        array): what SeedInit's per-range results travel with -- 10^7..10^8 seeds are GBs, not something to pickle."""
+        if self.world == 1:
+            return tuple(np.asarray(a) for a in arrays)
+        import torch
+        n = int(np.shape(arrays[0])[0])
+        sizes = [int(x) for x in self.allgather_obj(n)]
+        nmax, out = max(sizes), []
+        for a in arrays:
+            a = np.ascontiguousarray(a)
+            t = torch.zeros((nmax,) + a.shape[1:], dtype=torch.from_numpy(a[:0]).dtype, device=self._dev())
+            if n:
+                t[:n].copy_(torch.from_numpy(a))
+            bufs = [torch.empty_like(t) for _ in range(self.world)]
+            self.dist.all_gather(bufs, t)
+            out.append(np.concatenate([bufs[r][:sizes[r]].cpu().numpy() for r in range(self.world)], axis=0).astype(a.dtype, copy=False))
+        return tuple(out)
+
+    def bcast_arrays(self, arrays, src=0):
+        """tuple of numpy arrays from `src` to everyone as tensors (shapes and dtypes travel as a small object first)"""
+        if self.world == 1:
+            return arrays
+        import torch
+        meta = self.bcast_obj([(np.asarray(a).shape, np.asarray(a).dtype.str) for a in arrays] if self.rank == src else None, src)
+        out = []
+        for k, (shape, dt) in enumerate(meta):
+            a = np.ascontiguousarray(arrays[k]) if self.rank == src else np.empty(shape, dtype=np.dtype(dt))
+            t = torch.from_numpy(a).to(self._dev()) if a.size else torch.from_numpy(a)
+            if a.size:
+                self.dist.broadcast(t, src=src)
+            out.append(t.cpu().numpy() if a.size else a)
+        return tuple(out)
 
     def gather_rows(self, local, n_total):
         """rank 0: rows of every rank concatenated in rank (= buoy) order; others: None."""

@@ -213,8 +213,9 @@ def main(argv=None):
         pack = None
         if comm.root:
             with np.load(cf_npz_itm) as data:
-                pack = (int(data['nP']), data['xPosG0'], data['xPosC0'], data['IDs'], data['vJIt'], data['VRTCS'], data['idxKeep'])
-        nP, xPosG0, xPosC0, IDs, vJIt, VRTCS, idxK = comm.bcast_obj(pack)
+                pack = (data['xPosG0'], data['xPosC0'], data['IDs'], data['vJIt'], data['VRTCS'], data['idxKeep'])
+        xPosG0, xPosC0, IDs, vJIt, VRTCS, idxK = comm.bcast_arrays(pack)          # tensors, not pickles
+        nP = len(IDs)
     else:
         (xIC,) = records.fields(kstrt, ('siconc',))
         zt, zIDs, XseedG, XseedC = ncio.LoadNCdata(fNCseed, krec=jrecSeed)
@@ -223,10 +224,9 @@ def main(argv=None):
         lo, hi = comm.range(nP0)
         part = SeedInit(IDs[lo:hi], XseedG[lo:hi], XseedC[lo:hi], xlatT, xlonT, xYf, xXf, xResKM, imaskt,
                         xIceConc=np.asarray(xIC, dtype=np.float64), ctx=ctx)
-        parts = comm.allgather_obj((lo,) + part)
-        nP = sum(q[1] for q in parts)
-        xPosG0, xPosC0, IDs, vJIt, VRTCS = (np.concatenate([q[k] for q in parts], axis=0) for k in (2, 3, 4, 5, 6))
-        idxK = np.concatenate([q[0] + q[7] for q in parts])
+        # every rank's kept seeds, concatenated in rank (= seed) order: tensor all-gathers
+        xPosG0, xPosC0, IDs, vJIt, VRTCS, idxK = comm.allgather_rows(part[1:6] + (lo + part[6],))
+        nP = len(IDs)
         if nP < nP0:
             say(' *** `SeedInit()` had to cancel ' + str(nP0 - nP) + ' buoys! => nP = ' + str(nP))
         if comm.root:
@@ -298,6 +298,10 @@ def main(argv=None):
     def need_output(jrec):
         return lFull or (lUse2DTime and jrec in ends)
 
+    bcast = None
+    if a.full_records and comm.world > 1 and comm.backend == "nccl":
+        from .distributed import RecordBroadcaster
+        bcast = RecordBroadcaster(ctx)                 # rank 0 reads; one RCCL broadcast per record, overlapped with the stepping
     batches, jt = [], 0
     while jt < Nt:
         m = 1
@@ -330,8 +334,10 @@ def main(argv=None):
             elif comm.world == 1:
                 records.fields_rows_into(jrec, 0, Nj, ctx.stage(Nj))   # the whole record (:372-374)
                 ctx.submit(slot, 0)
+            elif bcast is not None:
+                bcast.deliver(slot, records.fields(jrec) if comm.root else None)
             else:
-                comm.deliver_record(ctx, slot, records.fields(jrec) if comm.root else None)   # rank 0 reads, RCCL broadcast
+                comm.deliver_record(ctx, slot, records.fields(jrec) if comm.root else None)   # gloo rehearsal: host broadcast
         clk.add("read_and_stage_records_s", t_up)
 
     tk = clk.add("setup_s", tk)
@@ -349,7 +355,12 @@ def main(argv=None):
             say(' *** records #%d..#%d/%d  dates = %s .. %s   (one fused launch)' % (jrec0 + 1, jrecN + 1, Nt0, epoch2clock(vTime[jt0]),
                                                                                    epoch2clock(vTime[jt0 + m - 1])))
         t_q = clk.now()
+        used = [(jt0 + r) % K for r in range(m)]
+        if bcast is not None:
+            bcast.before_run(used)
         trk.run(jrec0, jt0 % K, m)
+        if bcast is not None:
+            bcast.after_run(used)
         clk.add("enqueue_stepping_s", t_q)
         if ib + 1 < len(batches):
             upload(*batches[ib + 1])               # travels while the launch above runs
@@ -373,6 +384,8 @@ def main(argv=None):
                 zTim[1, sel[stepped[sel]]] = int(itime + rdt)
         clk.add("fetch_and_store_outputs_s", t_f)
     ctx.sync()
+    if bcast is not None:
+        bcast.close()
     clk.add("record_loop_s", t_loop)
     tk = clk.now()
     records.close()

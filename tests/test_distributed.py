@@ -97,6 +97,45 @@ def _sag_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _gather_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok = True
+        for nP in (0, 1, 2, 10, 1001):                      # fewer buoys than ranks, uneven ranges
+            lo, hi = sd.buoy_range(nP, rank, world)
+            full = {"f8": np.arange(2 * nP, dtype=np.float64).reshape(nP, 2) * 0.25, "i1": (np.arange(nP) % 3).astype(np.int8),
+                    "i8": (np.arange(2 * nP).reshape(nP, 2) + 2 ** 40).astype(np.int64), "i4": np.arange(nP, dtype=np.int32)}
+            for key, arr in full.items():
+                got = sd.gather_ranges(arr[lo:hi], nP)
+                if rank == 0:
+                    ok = ok and got.dtype == arr.dtype and got.shape == arr.shape and np.array_equal(got, arr)
+                else:
+                    ok = ok and got is None
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tensor_gather_of_buoy_ranges_world3():
+    """gather_ranges moves every rank's rows as one tensor (no pickled objects): three gloo ranks, uneven and empty
+    ranges, the dtypes the driver gathers (positions f8, masks i1, cells i8, ...)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(3)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r for r, _ in res) == [0, 1, 2] and all(ok for _, ok in res)
+
+
 def test_scatter_allgather_equals_broadcast_world3():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -161,6 +200,56 @@ def test_slot_tensor_broadcast_world1_rccl():
 
 
 @pytest.mark.gpu
+def test_record_broadcaster_overlapped_delivery_world1_rccl():
+    """distributed.RecordBroadcaster (what `--full-records` uses under torchrun): pinned staging -> slot on a
+    communication stream, RCCL broadcast in place, the compute stream ordered by events only; batches are delivered one
+    ahead of the launches that use them and slots are recycled.  One rank is all a one-GPU box allows RCCL; the result
+    must equal the oracle's."""
+    import torch
+    import torch.distributed as dist
+    import sitrack_amd as sit
+    from oracle import oracle as orc
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(_free_port()))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        Nj, Ni, K, Nt = 80, 96, 6, 36
+        grid = syn.make_grid(Nj, Ni, dkm=4.0, warp=1.0)
+        u, v, s = syn.make_fields(grid, K=Nt, seed=1, umax=0.8, drift=0.3)
+        s[:, 20:30, 40:60] = 0.02
+        _, yx = syn.make_buoys(grid, 20000, seed=3, frac=0.8)
+        trk = sit.IceTracker(grid["Yf"], grid["Xf"], grid["Yu"], grid["Xu"], grid["Yv"], grid["Xv"], grid["tmask"], nslots=K)
+        found, ji, _ = sit.FindContainingCell(yx, syn.nearest_t_plane(grid, yx), ctx=trk.ctx)
+        yx, ji = yx[found], ji[found]
+        trk.set_buoys(yx, ji)
+        ref = orc.Tracker(grid, yx, ji, nthreads=4)
+        bc = sd.RecordBroadcaster(trk.ctx)
+        m = K // 2
+        for r in range(m):
+            bc.deliver(r % K, (u[r], v[r], s[r]))
+        for b in range(Nt // m):
+            used = [(b * m + r) % K for r in range(m)]
+            bc.before_run(used)
+            trk.run(b * m, (b * m) % K, m)
+            bc.after_run(used)
+            if b + 1 < Nt // m:
+                for r in range((b + 1) * m, (b + 2) * m):
+                    bc.deliver(r % K, (u[r], v[r], s[r]))
+        bc.close()
+        for r in range(Nt):
+            ref.step(r, u[r], v[r], s[r], want_out=False)
+        st = trk.state()
+        assert np.array_equal(st["yx"], ref.pos) and np.array_equal(st["vJIt"], ref.jiT) and np.array_equal(st["iAlive"], ref.alive)
+        assert 0 < st["iAlive"].sum() < len(yx)
+        # the tensor gather on the device through RCCL (one rank: the whole set)
+        got = sd.gather_ranges(st["yx"], len(yx))
+        assert np.array_equal(got, st["yx"])
+        trk.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
 def test_bench_two_ranks_as_the_driver_launches_it():
     """bench.py under `python -m torch.distributed.run --nproc-per-node 2` (the driver's launch line), both ranks on the
     box's one GPU with gloo as transport (RCCL refuses two ranks per device): one JSON line from rank 0, whole-job value."""
@@ -180,6 +269,30 @@ def test_bench_two_ranks_as_the_driver_launches_it():
     assert d["n_gpus"] == 2 and d["steps"] == 40 and d["warmup"] == 8 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["buoys_per_gpu"] == 100000 and "broadcast from rank 0" in d["config"]["records_via"]
     assert abs(d["value"] - 2 * 100000 * 40 / (d["ms_per_step"] * 40e-3)) < 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
+def test_bench_multi_gpu_code_path_with_one_rccl_rank():
+    """What `bench.py --gpus N` does beyond one GPU -- RCCL process group, records broadcast in place into the resident
+    slots, max-over-ranks reductions, and the short end-to-end segment (one broadcast per record overlapped with the
+    stepping, RCCL broadcast and scatter + all-gather) -- rehearsed with ONE RCCL rank (all a one-GPU box allows), checked
+    against the oracle by the run's own --check."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SITRK_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, "bench.py", "--config", "c2", "--steps", "96", "--warmup", "8", "--no-cpu-baseline", "--check"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "check OK" in r.stderr
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert "RCCL broadcast" in d["config"]["records_via"]
+    e = d["e2e_broadcast"]
+    assert "error" not in e, e
+    for mode in ("broadcast", "scatter_allgather"):
+        assert e[mode]["ms_per_step"] > 0 and e[mode]["particle_steps_per_s"] > 0
+    assert e["slab_bytes"] == 3 * 512 * 512 * 4
 
 
 @pytest.mark.gpu
