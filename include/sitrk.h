@@ -146,6 +146,11 @@ int sitrk_commit_record_rows(sitrk_t *h, int slot, int j0, int j1);
 int sitrk_set_buoys(sitrk_t *h, int64_t nP, const double *yx, const int32_t *jiT,
                     const int32_t *rec_first, const int32_t *rec_last);
 
+/* Buoys that arrive with a history (handed over by another rank when the ranks' latitude bands are re-balanced): right after
+ * sitrk_set_buoys, mark the buoys with alive[k] == 0 as dead and give every buoy its kill record back (kill_rec[k], -1 =
+ * alive), so that sitrk_fetch / sitrk_fetch_record answer as they did on the rank that stepped them before. */
+int sitrk_restore_state(sitrk_t *h, const int8_t *alive, const int32_t *kill_rec);
+
 /* re-order the device-resident buoys by host cell (coalescing); results are
  * always returned in the caller's original order.  resort_every > 0 re-sorts
  * automatically every that many steps (default 512; 0 = never). */

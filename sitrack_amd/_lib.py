@@ -46,6 +46,7 @@ _SIGNATURES = {
     "sitrk_record_ptr": (_vp, [_vp, _int]),
     "sitrk_commit_record": (_int, [_vp, _int]),
     "sitrk_set_buoys": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "sitrk_restore_state": (_int, [_vp, _vp, _vp]),
     "sitrk_sort_buoys": (_int, [_vp]),
     "sitrk_set_resort": (_int, [_vp, _int]),
     "sitrk_step": (_int, [_vp, _int, _int]),
@@ -302,6 +303,12 @@ class Context:
         self.nP = nP
         if sort:
             self.sort_buoys()
+
+    def restore_state(self, alive, kill_rec):
+        """after set_buoys(sort=False): dead flags and kill records of buoys that were stepped elsewhere before"""
+        al = as_c(alive, np.int8, (self.nP,), "alive")
+        kr = as_c(kill_rec, np.int32, (self.nP,), "kill_rec")
+        self._chk(self._L.sitrk_restore_state(self._h, _ptr(al), _ptr(kr)))
 
     def sort_buoys(self):
         self._chk(self._L.sitrk_sort_buoys(self._h))

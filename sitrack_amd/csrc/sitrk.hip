@@ -44,6 +44,7 @@ static int fail(sitrk_ctx *h, int code, const char *fmt, ...)
     } while (0)
 
 static inline unsigned nblocks(int64_t n, int bs = kBlock) { return (unsigned)((n + bs - 1) / bs); }
+static inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 template <typename T>
 static hipError_t dev_alloc(T **p, size_t count)
@@ -591,6 +592,31 @@ SITRK_API int sitrk_set_buoys(sitrk_t *h, int64_t nP, const double *yx, const in
     return SITRK_OK;
 }
 
+SITRK_API int sitrk_restore_state(sitrk_t *h, const int8_t *alive, const int32_t *kill_rec)
+{
+    NEED(h, "null handle");
+    NEED(h->st[0].pos, "sitrk_restore_state: call sitrk_set_buoys first");
+    NEED(alive && kill_rec, "sitrk_restore_state: null array");
+    const int64_t nP = h->nP;
+    if (nP == 0) return SITRK_OK;
+    HIPCHK(hipSetDevice(h->device));
+    const size_t b_a = align256((size_t)nP), b_k = align256((size_t)nP * 4);
+    int rc = ensure_scratch(h, b_a + b_k);
+    if (rc) return rc;
+    char *w = (char *)h->scratch;
+    HIPCHK(hipMemcpyAsync(w, alive, (size_t)nP, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(w + b_a, kill_rec, (size_t)nP * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(h->counter, 0, sizeof(unsigned long long), h->stream));
+    hipLaunchKernelGGL(restore_state_kernel, dim3(nblocks(nP)), dim3(kBlock), 0, h->stream, nP, h->st[h->cur], (const int8_t *)w,
+                       (const int32_t *)(w + b_a), h->counter);
+    HIPCHK(hipGetLastError());
+    unsigned long long rim = 0;
+    HIPCHK(hipMemcpyAsync(&rim, h->counter, sizeof(rim), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));          // the caller's arrays are its own again
+    h->rim_buoys = rim != 0;                          // dead buoys sit where they died, often in the rim: they never step
+    return SITRK_OK;
+}
+
 SITRK_API int sitrk_set_resort(sitrk_t *h, int resort_every)
 {
     NEED(h, "null handle");
@@ -809,8 +835,6 @@ SITRK_API int sitrk_launch_stats(sitrk_t *h, int reset, int64_t *fused_launches,
 }
 
 // --------------------------------------------------------------------------- fetch
-static inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
-
 SITRK_API int sitrk_fetch(sitrk_t *h, double *yx, int32_t *jiT, int8_t *alive, int32_t *kill_rec)
 {
     NEED(h, "null handle");

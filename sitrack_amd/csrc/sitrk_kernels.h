@@ -933,6 +933,19 @@ __global__ void permute_state_kernel(int64_t n, const int32_t *__restrict__ src,
     }
 }
 
+// buoys handed over with a history (migration between ranks): slot s holds the caller's buoy perm[s]
+__global__ void restore_state_kernel(int64_t n, BuoyState st, const int8_t *__restrict__ alive, const int32_t *__restrict__ kill_rec,
+                                     unsigned long long *__restrict__ rim_alive)
+{
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int32_t o = st.perm[s];
+    int32_t c = st.cell[s];
+    if (!alive[o]) st.cell[s] = c | SITRK_DEAD_BIT;
+    else if (cell_j(c) < 2 || cell_i(c) < 2) atomicOr(rim_alive, 1ull);      // a LIVE buoy in the two outermost rows/columns
+    st.kill_rec[s] = kill_rec[o];
+}
+
 // ---------------------------------------------------------------------------
 // fetch: sorted slots -> caller order
 // ---------------------------------------------------------------------------

@@ -291,6 +291,59 @@ class Comm:
             out.append(np.concatenate([bufs[r][:sizes[r]].cpu().numpy() for r in range(self.world)], axis=0).astype(a.dtype, copy=False))
         return tuple(out)
 
+    def alltoall_rows(self, chunks):
+        """`chunks[d]` = tuple of arrays (common number of rows) for rank d; returns, per array position, the
+        concatenation of what every rank sent here, in source-rank order.  RCCL: one `all_to_all_single` per array with
+        the row counts exchanged first; gloo has no all-to-all: pairwise isend / irecv."""
+        import torch
+        W, me = self.world, self.rank
+        narr = len(chunks[0])
+        send_n = [int(np.shape(chunks[d][0])[0]) for d in range(W)]
+        if W == 1:
+            return tuple(np.asarray(a) for a in chunks[0])
+        cnt = torch.tensor(send_n, dtype=torch.int64, device=self._dev())
+        rcv = torch.empty(W, dtype=torch.int64, device=self._dev())
+        if self.backend == "nccl":
+            self.dist.all_to_all_single(rcv, cnt)
+        else:
+            bufs = [torch.empty(W, dtype=torch.int64) for _ in range(W)]
+            self.dist.all_gather(bufs, cnt)
+            rcv = torch.stack([b[me] for b in bufs])
+        recv_n = [int(x) for x in rcv.cpu()]
+        out = []
+        for k in range(narr):
+            parts = [np.ascontiguousarray(chunks[d][k]) for d in range(W)]
+            tail, dt = parts[0].shape[1:], parts[0].dtype
+            width = int(np.prod(tail)) if tail else 1
+            if self.backend == "nccl":
+                tin = torch.from_numpy(np.concatenate(parts, axis=0)).cuda()
+                tout = torch.empty((sum(recv_n),) + tail, dtype=tin.dtype, device="cuda")
+                self.dist.all_to_all_single(tout, tin, output_split_sizes=recv_n, input_split_sizes=send_n)
+                out.append(tout.cpu().numpy())
+            else:
+                got = [np.empty((recv_n[s],) + tail, dtype=dt) for s in range(W)]
+                got[me] = parts[me]
+                reqs = []
+                for off in range(1, W):                       # round `off`: send to me+off, receive from me-off
+                    d, src = (me + off) % W, (me - off) % W
+                    if send_n[d] * width:
+                        reqs.append(self.dist.isend(torch.from_numpy(parts[d]), dst=d))
+                    if recv_n[src] * width:
+                        reqs.append(self.dist.irecv(torch.from_numpy(got[src]), src=src))
+                for r in reqs:
+                    r.wait()
+                out.append(np.concatenate(got, axis=0))
+        return tuple(out)
+
+    def allreduce_sum(self, a):
+        """element-wise sum over the ranks of an int64 / float64 array (returned on every rank)"""
+        if self.world == 1:
+            return np.asarray(a)
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(self._dev())
+        self.dist.all_reduce(t)
+        return t.cpu().numpy()
+
     def bcast_arrays(self, arrays, src=0):
         """tuple of numpy arrays from `src` to everyone as tensors (shapes and dtypes travel as a small object first)"""
         if self.world == 1:

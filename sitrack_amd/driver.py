@@ -20,7 +20,7 @@ from os import path
 import numpy as np
 
 from . import _lib, ncio
-from .distributed import Comm
+from .distributed import Comm, all_ranges
 from .tracking import GetTimeSpan, IceTracker, SeedInit
 
 rdt = 3600.          # time step [s] = model output period (reference :31)
@@ -59,6 +59,10 @@ def parse_args(argv=None):
     ap.add_argument('--slots', type=int, default=32,
                     help='model records resident on the GPU (extra): up to half of them are advanced by one fused launch '
                          'whenever no per-record output is due, while the next ones are read and uploaded')
+    ap.add_argument('--rebalance', type=int, default=256,
+                    help='under torchrun: every so many records the buoys are re-partitioned over the ranks by their CURRENT host '
+                         'row (migration of the states between ranks), so that every rank keeps a compact latitude band to read '
+                         '(extra; 0 = never; same results)')
     ap.add_argument('--full-records', action='store_true',
                     help='read and upload whole records (under torchrun: rank 0 reads, RCCL broadcast) instead of only the rows '
                          'each rank\'s buoys can touch (extra; same results)')
@@ -252,13 +256,14 @@ def main(argv=None):
     #      latitude band: with row-band ingest each rank then reads only its own rows of every record, no collective.
     order = np.arange(nP) if comm.world == 1 else np.argsort(vJIt[:, 0], kind='stable')
     lo, hi = comm.range(nP)
-    mine = order[lo:hi]
+    part = {"order": order, "mine": order[lo:hi]}          # who owns what; re-made by rebalance()
+    mine = part["mine"]
 
     def to_caller_order(rows):            # rows gathered in rank order -> the caller's buoy order
         if rows is None or comm.world == 1:
             return rows
         out = np.empty_like(rows)
-        out[order] = rows
+        out[part["order"]] = rows
         return out
 
     (u0,) = records.fields(kstrt, ('u_ice',))
@@ -342,6 +347,55 @@ def main(argv=None):
 
     tk = clk.add("setup_s", tk)
     t_loop = clk.now()
+    def rebalance():
+        """Re-partition the buoys over the ranks by their CURRENT host row (migration / re-balancing).
+        Each rank fetches its buoys' state, a global histogram of host rows fixes every buoy's place in the new order --
+        by (row, owning rank, local order) -- hence its new owner; the states travel in one all-to-all of 50-byte rows and
+        every rank re-creates its buoy set with their history (dead flags, kill records).  Trajectories do not depend on
+        who steps a buoy; only the rows a rank has to read do."""
+        st = ctx.fetch()
+        mine_g = part["mine"]
+        rows = st["jiT"][:, 0].astype(np.int64)
+        hist = np.bincount(rows, minlength=Nj).astype(np.int64)
+        allh = comm.allgather_rows((hist[None, :],))[0]                        # (world, Nj)
+        before_row = np.concatenate([[0], np.cumsum(allh.sum(axis=0))[:-1]])    # buoys in lower rows
+        before_rank = allh[:comm.rank].sum(axis=0)                              # same row, lower ranks
+        o = np.argsort(rows, kind='stable')
+        within = np.empty(len(rows), dtype=np.int64)
+        starts = np.concatenate([[0], np.cumsum(hist)[:-1]])
+        within[o] = np.arange(len(rows)) - starts[rows[o]]                      # same row, this rank, local order
+        newpos = before_row[rows] + before_rank[rows] + within                  # place in the new global order
+        ends = np.array([hi_ for _, hi_ in all_ranges(nP, comm.world)])         # the new owner: whose range the place falls in
+        dest = np.searchsorted(ends, newpos, side='right')
+        f8 = np.concatenate([st["yx"], newpos[:, None].astype(np.float64)], axis=1)          # positions travel exactly
+        win = (z1stModelRec[mine_g], zLstModelRec[mine_g]) if lUse2DTime else (np.zeros(len(rows), dtype=int),) * 2
+        i8 = np.stack([mine_g.astype(np.int64), st["jiT"][:, 0].astype(np.int64), st["jiT"][:, 1].astype(np.int64),
+                       st["alive"].astype(np.int64), st["kill_rec"].astype(np.int64), np.asarray(win[0], dtype=np.int64),
+                       np.asarray(win[1], dtype=np.int64)], axis=1)
+        part["rebalances"] = part.get("rebalances", 0) + 1
+        part["migrated"] = part.get("migrated", 0) + comm.sum_int(int((dest != comm.rank).sum()))
+        chunks = [(f8[dest == d], i8[dest == d]) for d in range(comm.world)]
+        rf8, ri8 = comm.alltoall_rows(chunks)
+        k = np.argsort(rf8[:, 2], kind='stable')                               # the new order inside this rank's range
+        rf8, ri8 = rf8[k], ri8[k]
+        part["mine"] = ri8[:, 0].copy()
+        ctx.set_buoys(np.ascontiguousarray(rf8[:, :2]), ri8[:, 1:3].astype(np.int32),
+                      ri8[:, 5].astype(np.int32) if lUse2DTime else None, ri8[:, 6].astype(np.int32) if lUse2DTime else None, sort=False)
+        ctx.restore_state(ri8[:, 3].astype(np.int8), ri8[:, 4].astype(np.int32))
+        ctx.sort_buoys()
+        allmine = comm.gather_rows(part["mine"], nP)
+        if comm.root:
+            part["order"] = allmine
+        band["age"] = None                                                      # the rows this rank reads start over
+
+    due, since = [], 0
+    for (jt0, m) in batches:              # after which batches the ranks re-balance: a function of the record count alone
+        since += m
+        due.append(comm.world > 1 and a.rebalance > 0 and since >= a.rebalance)
+        if due[-1]:
+            since = 0
+    if due:
+        due[-1] = False
     if batches:
         upload(*batches[0])
     for ib, (jt0, m) in enumerate(batches):
@@ -362,7 +416,7 @@ def main(argv=None):
         if bcast is not None:
             bcast.after_run(used)
         clk.add("enqueue_stepping_s", t_q)
-        if ib + 1 < len(batches):
+        if ib + 1 < len(batches) and not due[ib]:
             upload(*batches[ib + 1])               # travels while the launch above runs
         jt, jrec, itime = jt0 + m - 1, jrecN, vTime[jt0 + m - 1]
         need = need_output(jrec)
@@ -383,6 +437,11 @@ def main(argv=None):
                 zMSK[1, sel] = msk[sel]
                 zTim[1, sel[stepped[sel]]] = int(itime + rdt)
         clk.add("fetch_and_store_outputs_s", t_f)
+        if due[ib]:
+            t_r = clk.now()
+            rebalance()
+            clk.add("rebalance_s", t_r)
+            upload(*batches[ib + 1])
     ctx.sync()
     if bcast is not None:
         bcast.close()
@@ -429,4 +488,5 @@ def main(argv=None):
     clk.t["total_s"] = clk.now() - clk.t0
     comm.close()
     return {"files": outs, "nP": nP, "IDs": IDs, "vJIt": vJIt_end, "iAlive": alive_end, "Nt": Nt, "kstrt": kstrt,
-            "timing": dict(clk.t), "launches": launches}
+            "timing": dict(clk.t), "launches": launches,
+            "rebalances": part.get("rebalances", 0), "migrated": part.get("migrated", 0)}

@@ -119,6 +119,46 @@ def _gather_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _a2a_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from sitrack_amd.distributed import Comm
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), SITRK_DIST_BACKEND="gloo")
+    comm = Comm()
+    try:
+        rng = np.random.default_rng(100 + rank)
+        n = [0, 7, 1000][rank]                                  # one rank has nothing to send
+        f8 = rng.random((n, 3)); i8 = rng.integers(0, 1 << 40, (n, 2)); tag = np.full(n, rank, dtype=np.int64)
+        dest = rng.integers(0, world, n)
+        got_f8, got_i8, got_tag = comm.alltoall_rows([(f8[dest == d], i8[dest == d], tag[dest == d]) for d in range(world)])
+        # everybody tells everybody what they sent where: the expected result on each rank
+        everything = comm.allgather_obj((f8, i8, dest))
+        want_f8 = np.concatenate([e[0][e[2] == rank] for e in everything])
+        want_i8 = np.concatenate([e[1][e[2] == rank] for e in everything])
+        ok = np.array_equal(got_f8, want_f8) and np.array_equal(got_i8, want_i8) and np.all(np.diff(got_tag) >= 0)
+        s = comm.allreduce_sum(np.array([rank + 1, 10], dtype=np.int64))
+        ok = ok and list(s) == [6, 30]
+        q.put((rank, bool(ok)))
+    finally:
+        comm.close()
+
+
+def test_alltoall_rows_world3_gloo():
+    """the migration primitive of the re-balancing (Comm.alltoall_rows): rows for every destination, received in
+    source-rank order; gloo has no all-to-all, so this is the isend / irecv form"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_a2a_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(3)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r for r, _ in res) == [0, 1, 2] and all(ok for _, ok in res)
+
+
 def test_tensor_gather_of_buoy_ranges_world3():
     """gather_ranges moves every rank's rows as one tensor (no pickled objects): three gloo ranks, uneven and empty
     ranges, the dtypes the driver gathers (positions f8, masks i1, cells i8, ...)."""

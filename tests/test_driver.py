@@ -461,14 +461,18 @@ def _dist_worker(rank, world, port, tmp, argv, q):
     os.chdir(tmp)
     out = drv.main(argv)
     if rank == 0:
-        q.put({k: out[k] for k in ("files", "nP", "IDs", "vJIt", "iAlive")})
+        q.put({k: out[k] for k in ("files", "nP", "IDs", "vJIt", "iAlive", "rebalances", "migrated")})
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("two_d_time,extra", [(False, []), (True, []), (False, ["--full-records"])])
+@pytest.mark.parametrize("two_d_time,extra", [(False, []), (True, []), (False, ["--full-records"]),
+                                              (False, ["--rebalance", "3"]), (True, ["--rebalance", "4"])])
 def test_cli_two_ranks_equals_one(tmp_path, monkeypatch, two_d_time, extra):
     """N>1 driver path rehearsed with 2 ranks on the one GPU of the box (gloo moves the record slabs; RCCL refuses
-    two ranks per device): buoy-range partition, per-range SeedInit, record delivery, gathers -> same files."""
+    two ranks per device): buoy-range partition, per-range SeedInit, record delivery, gathers -> same files.
+    `--rebalance R`: every R records the buoys are re-partitioned by their current host row and their states migrate
+    between the ranks (the fast field of the test case carries buoys across the band boundary, and some die) -- the
+    files must still be identical to the single-rank run's, byte for byte in every variable."""
     import socket
     import torch.multiprocessing as mp
     d1, d2 = tmp_path / "one", tmp_path / "two"
@@ -491,6 +495,8 @@ def test_cli_two_ranks_equals_one(tmp_path, monkeypatch, two_d_time, extra):
     assert two["nP"] == one["nP"] and np.array_equal(two["IDs"], one["IDs"])
     assert np.array_equal(two["vJIt"], one["vJIt"]) and np.array_equal(two["iAlive"], one["iAlive"])
     assert two["files"] == one["files"]
+    if "--rebalance" in extra:
+        assert two["rebalances"] >= 1 and two["migrated"] > 0, (two["rebalances"], two["migrated"])      # buoys did change owner
     for f in one["files"]:
         a = ncio.LoadNCdata(str(d1 / f), krec=-1, lmask=True)
         b = ncio.LoadNCdata(str(d2 / f), krec=-1, lmask=True)
