@@ -335,6 +335,12 @@ def _wlib():
         "H5Awrite": (C.c_int, [hid_t, hid_t, C.c_void_p]),
         "H5Gopen2": (hid_t, [hid_t, C.c_char_p, hid_t]), "H5Gclose": (C.c_int, [hid_t]),
     }
+    try:                                 # direct chunk write (HDF5 >= 1.10.3): chunks deflated by our own threads
+        L.H5Dwrite_chunk.restype = C.c_int
+        L.H5Dwrite_chunk.argtypes = [hid_t, hid_t, C.c_uint32, C.POINTER(hsize_t), C.c_size_t, C.c_void_p]
+        L._has_chunk_write = True
+    except AttributeError:
+        L._has_chunk_write = False
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
         fn.restype, fn.argtypes = res, args
@@ -432,6 +438,8 @@ class NC4Writer:
         if d < 0:
             raise OSError("H5Dcreate2(%s) failed" % name)
         self.vars[name] = (d, key, tuple(dims))
+        self.layout = getattr(self, "layout", {})
+        self.layout[name] = (tuple(chunk), int(complevel), fill_value) if ((unlimited or zlib) and zlib) else None
         if fill_value is not None:
             self._attr(d, "_FillValue", np.asarray([fill_value], dtype=np.dtype(key)))
         return name
@@ -439,8 +447,38 @@ class NC4Writer:
     def write(self, name, data):
         d, key, dims = self.vars[name]
         a = np.ascontiguousarray(data, dtype=np.dtype(key))
+        lay = self.layout.get(name)
+        if lay is not None and a.ndim == 2 and a.size >= (1 << 20) and self.L._has_chunk_write and a.dtype.isnative:
+            return self._write_chunks_parallel(d, a, *lay)
         if self.L.H5Dwrite(d, self.L._native[key], 0, 0, 0, a.ctypes.data_as(C.c_void_p)) < 0:
             raise OSError("H5Dwrite(%s) failed" % name)
+
+    def _write_chunks_parallel(self, d, a, chunk, level, fill):
+        """Shuffle + deflate of every (1 x C) chunk on a thread pool (zlib releases the GIL), raw chunks handed to
+        H5Dwrite_chunk: the file is what H5Dwrite's filter pipeline would have produced, in a fraction of the time --
+        libhdf5 deflates one chunk after the other on the calling thread, 45 s for the 10^7-buoy files at level 9."""
+        import zlib
+        from concurrent.futures import ThreadPoolExecutor
+        nrec, n = a.shape
+        cw = chunk[1]
+        isz = a.dtype.itemsize
+        jobs = [(r, c0) for r in range(nrec) for c0 in range(0, n, cw)]
+
+        def pack(job):
+            r, c0 = job
+            seg = a[r, c0:c0 + cw]
+            if seg.shape[0] < cw:                                  # an edge chunk is stored whole
+                pad = np.full(cw, 0 if fill is None else fill, dtype=a.dtype)
+                pad[:seg.shape[0]] = seg
+                seg = pad
+            shuffled = np.ascontiguousarray(seg.view(np.uint8).reshape(cw, isz).T)      # the SHUFFLE filter: byte planes
+            return job, zlib.compress(shuffled.tobytes(), level)
+        nthreads = min(16, os.cpu_count() or 1, len(jobs))
+        with ThreadPoolExecutor(nthreads) as ex:
+            for (r, c0), blob in ex.map(pack, jobs):
+                off = (hsize_t * 2)(r, c0)
+                if self.L.H5Dwrite_chunk(d, 0, 0, off, len(blob), blob) < 0:
+                    raise OSError("H5Dwrite_chunk failed at (%d,%d)" % (r, c0))
 
     def close(self):
         """Turn the coordinate variables into dimension scales, attach every variable to its scales, close."""
