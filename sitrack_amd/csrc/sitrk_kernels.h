@@ -497,7 +497,8 @@ struct CellCtx {
                                         // (32 bits: sitrk_set_grid keeps Nj*Ni*8 below 2^32) -> a record's velocities are
                                         // loaded as (scalar record pointer + this offset), no address arithmetic per record
     pt F11, U11, V11, F10, U10, F01, V01, F00;
-    bool sFV, sFU;                      // ccw(F11,V01,V11), ccw(F11,U10,U11)
+    unsigned ori;                       // the cell's orientation byte as loaded: bit 0 = ccw(F11,V01,V11), bit 1 = ccw(F11,U10,U11);
+                                        // unpacked where it is used, one record later, not behind its own load in the crossing path
 };
 
 // all eight points from two 32-bit byte offsets (the cell's record and the one a row below) + immediates
@@ -511,9 +512,7 @@ __device__ __forceinline__ void load_ctx(const StepArgs &a, const char *__restri
     x.F10 = geo_pt(gb, k48, -48); x.U10 = geo_pt(gb, k48, -32);
     x.F01 = geo_pt(gb, k48b, 0); x.V01 = geo_pt(gb, k48b, 32);
     x.F00 = geo_pt(gb, k48b, -48);
-    const int8_t ori = a.orient[kcell];
-    x.sFV = (ori & 1) != 0;             // ccw(F11, V01, V11)
-    x.sFU = (ori & 2) != 0;             // ccw(F11, U10, U11)
+    x.ori = (unsigned)(uint8_t)a.orient[kcell];
 }
 
 // ---------------------------------------------------------------------------
@@ -555,12 +554,10 @@ __device__ __forceinline__ void load_ctx_lds(const StepArgs &a, const Patch &pa,
     x.o1 = kcell * ES; x.o0 = (kcell - Ni) * ES;
     const unsigned k48 = kcell * (unsigned)sizeof(CellGeo), k48b = k48 - Ni * (unsigned)sizeof(CellGeo);
     x.U11 = geo_pt(gb, k48, 16); x.V11 = geo_pt(gb, k48, 32); x.U10 = geo_pt(gb, k48, -32); x.V01 = geo_pt(gb, k48b, 32);
-    const int8_t ori = a.orient[kcell];
+    x.ori = (unsigned)(uint8_t)a.orient[kcell];
     const unsigned lob = lo - (unsigned)pa.PC * (unsigned)sizeof(pt);
     x.F11 = lds_pt(s_geo, lo, 0); x.F10 = lds_pt(s_geo, lo, -16);
     x.F01 = lds_pt(s_geo, lob, 0); x.F00 = lds_pt(s_geo, lob, -16);
-    x.sFV = (ori & 1) != 0;
-    x.sFU = (ori & 2) != 0;
 }
 
 // resolve_crossing_tab() with every point read from the patch: same predicates, same operands, same order.
@@ -707,8 +704,9 @@ __global__ __launch_bounds__(kBlock, SITRK_RUN_WAVES) void advect_run_kernel(Run
         } else {                                         // :427-441
             // all four candidates are requested up front (pin_load: none is sunk into the branch that selects it)
             // intersect2Seg(P,F,C,D) = (ccw(P,C,D) != ccw(F,C,D)) and (ccw(P,F,C) != ccw(P,F,D)); ccw(F,C,D) is per cell
-            const bool llum1 = (ccw(P, x.V01, x.V11) != x.sFV) && (ccw(P, x.F11, x.V01) != ccw(P, x.F11, x.V11));
-            const bool llvm1 = (ccw(P, x.U10, x.U11) != x.sFU) && (ccw(P, x.F11, x.U10) != ccw(P, x.F11, x.U11));
+            const bool sFV = (x.ori & 1u) != 0, sFU = (x.ori & 2u) != 0;
+            const bool llum1 = (ccw(P, x.V01, x.V11) != sFV) && (ccw(P, x.F11, x.V01) != ccw(P, x.F11, x.V11));
+            const bool llvm1 = (ccw(P, x.U10, x.U11) != sFU) && (ccw(P, x.F11, x.U10) != ccw(P, x.F11, x.U11));
             pin_load(fu0); pin_load(fv0);
             zU = llum1 ? (double)fu0 : (double)fu1;
             zV = llvm1 ? (double)fv0 : (double)fv1;
