@@ -3,30 +3,30 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one model record applied to every buoy of the batch.  By default
-`sitrk_run` advances 32 resident records per launch (advect_run_kernel: loop
-interchange, every buoy still takes every step; `--fuse 1` = one launch of
-advect_step_kernel per record, also timed in the same run and reported under
-`per_record_launch`).  Workload at N=1 = BASELINE.json configs[2] (C3,
-the one the metric is quoted on): synthetic regular 4096x4096 C-grid (4 km),
-1e7 random buoys in the central 60 %, 32 device-resident fp32 records (solid-body
-rotation + per-record drift; the survey keeps 8 resident -- the same
-kernel at 8 records per launch is reported under `eight_records_per_launch`) cycled.  N>1: one process per GPU,
-each rank owns a contiguous range of 1e7 buoys of the N*1e7 set (weak scaling),
-the record slabs are generated on rank 0 and broadcast over RCCL into every
-rank's resident slots (the path's only exchange step); stepping needs no
-collective.
+A "step" is one model record applied to every buoy of the batch.  `sitrk_run` advances 32 resident records per launch
+(advect_run_kernel: loop interchange, every buoy still takes every step -- the form the command line runs too); the same
+K steps with one launch of advect_step_kernel per record and with 8 records per launch are timed in the same run and
+reported under `per_record_launch` / `eight_records_per_launch`.
 
-Prints ONE JSON line (rank 0).  `roofline.achieved` = ALGORITHMIC bytes per launch
-over the average launch duration measured with HIP events on the library's own
-stream.  Algorithmic bytes follow SURVEY.md 8(d) -- 50 B of state per buoy + 56 B
-(48 B geometry + u,v) per grid cell the step needs -- but count only the cells the
-buoys' 2x2 stencils actually touch (the buoys fill the central 60 % of the domain):
-charging all Nj*Ni cells, as the survey's closed form does, over-counts by 0.6 GB per
-step and would put the kernel above the HBM peak.  The survey's figure is kept in
-`roofline.survey_formula_*` for reference.  `cpu_baseline` = the CPU
-oracle (oracle/sitrk_oracle.c, a port of the reference loop, OpenMP over buoys)
-timed on this box's host cores on a bounded sample of the same workload.
+Workload: N = 1 -> BASELINE.json configs[2] (C3, the one the metric is quoted on): synthetic regular 4096x4096 C-grid
+(4 km), 1e7 random buoys in the central 60 %, 32 device-resident fp32 records (solid-body rotation + per-record drift,
+SURVEY.md 8d) cycled.  N > 1 -> configs[3] (C4): one process per GPU, each rank owns 1.25e7 buoys (1e8 over 8 GPUs; weak
+scaling), the record slabs are generated on rank 0 and broadcast over RCCL in place into every rank's resident slots;
+stepping needs no collective.  `c2` = configs[1] measured on the same GPU in the same process.
+
+Prints ONE JSON line (rank 0).
+ * `roofline` of the fused kernel: bound "fp64_valu_issue"; achieved = VALU instructions per second (instructions per wave
+   and record from the committed rocprofv3 counters in profiles/traffic.json x waves x records really advanced, counted by
+   the library: sitrk_launch_stats) against 1024 SIMDs x 2.4 GHz / 4 cycles; `traffic` = measured fabric bytes per launch
+   (FETCH_SIZE x 2 + WRITE_SIZE of the same command, profiles/); `hbm` = the algorithmic-byte view (secondary: the kernel
+   is not HBM bound).  Algorithmic bytes follow SURVEY.md 8(d) -- 50 B of state per buoy + 56 B (48 B geometry + u,v) per
+   grid cell a step needs -- counting the cells the buoys' 2x2 stencils touch (the buoys fill the central 60 %; charging all
+   Nj*Ni cells would put the one-record kernel above the HBM peak; that figure is kept as survey_formula_*).
+ * `per_record_launch.roofline`: bound "hbm", algorithmic bytes of one record over the measured launch time.
+ * `cpu_baseline`: the CPU oracle (oracle/sitrk_oracle.c, a port of the reference loop, OpenMP over buoys) timed on this
+   box's host cores on a bounded sample of the same workload.
+ * N > 1: `e2e_broadcast` = a short segment with ONE broadcast of every record's slab per step overlapped with the
+   stepping (RCCL broadcast and scatter + all-gather), next to the resident `value`.
 """
 import argparse
 import json

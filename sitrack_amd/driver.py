@@ -69,30 +69,30 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def seed_name_tokens(fNCseedBN):
-    """`cdtbin`, `csfkm` from the seeding file NAME (reference :115-148)."""
-    stem = fNCseedBN.split('.')[0].split('_')
-    csfkm = ''
-    if len(stem) > 2 and stem[2] in ('nemoTsi3', 'nemoTmm', 'sidfex'):
-        cdtbin = '_idlSeed'
-        for ii in (1, 2, 3):
-            ckm = '_' + stem[-ii]
-            if ckm[-2:] == 'km':
-                csfkm = ckm
-                break
-    else:
-        toks = fNCseedBN.split('.')[-2].split('_')
-        itst, lok = 1, False
-        while not lok:
-            itst -= 1
-            csfkm = '_' + toks[itst]
-            cdtbin = '_' + toks[-3 + itst]
-            lok = (csfkm[-2:] == 'km' and cdtbin[1:3] == 'dt') or (cdtbin[1:3] == 'dt' and itst == 0)
-            if itst < -4:
-                raise ValueError('could not figure out `csfkm` and `cdtbin` from file name! %s %s' % (csfkm, cdtbin))
-        if itst == 0:
-            csfkm = ''
-    return cdtbin, csfkm
+_IDEALISED_KINDS = ('nemoTsi3', 'nemoTmm', 'sidfex')
+
+
+def seed_name_tokens(seed_file_name):
+    """The two tags the output names inherit from the seeding file's NAME (behaviour of reference
+    si3_part_tracker.py:115-148): the time-bin tag and the resolution tag, each with its leading underscore.
+
+    * idealised seeding (`sitrack_seeding_<kind>_...`, kind = nemoTsi3 / nemoTmm / sidfex): time-bin tag `_idlSeed`;
+      the resolution tag is the last of the final three `_`-separated tokens that ends in `km`, if any;
+    * otherwise (RGPS-style selections, `..._dt72_..._10km.nc`): the time-bin token `dt<h>` sits three places before the
+      resolution token `<n>km`, which is among the last four tokens; a name without resolution token has its `dt<h>`
+      third from the end and yields an empty resolution tag.  Anything else is an error, like in the reference."""
+    head = seed_file_name.split('.')[0].split('_')
+    if len(head) > 2 and head[2] in _IDEALISED_KINDS:
+        km = next((tok for tok in reversed(head[-3:]) if tok.endswith('km')), None)
+        return '_idlSeed', ('_' + km) if km else ''
+    toks = seed_file_name.split('.')[-2].split('_')
+    if toks[-3].startswith('dt'):                      # no resolution token at the end
+        return '_' + toks[-3], ''
+    for back in range(1, 5):
+        res, dtbin = toks[-back], toks[-back - 3]
+        if res.endswith('km') and dtbin.startswith('dt'):
+            return '_' + dtbin, '_' + res
+    raise ValueError('could not figure out the resolution and time-bin tags from the file name %s' % seed_file_name)
 
 
 def date_tag(it):

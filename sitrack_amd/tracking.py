@@ -36,23 +36,21 @@ def vertices_of(jiT):
 
 
 def GetTimeSpan(dt, vtime_mod, iSdA, iMdA, iMdB, iStop=None, iverbose=0):
-    """Reference sitrack/tracking.py:8-37 (host logic).  Raises instead of `exit(0)`."""
-    vtime_mod = np.asarray(vtime_mod)
-    if iSdA < iMdA - dt / 2 or iSdA > iMdB - dt / 2:
+    """First and last model record of a run (reference sitrack/tracking.py:8-37, same arguments and 5-tuple; raises where
+    the reference prints and exits).  `vtime_mod` holds the record centres, the seeding date `iSdA` must fall inside the
+    model span shifted back by half a step; the run starts at the first record centred strictly after the seeding date
+    and ends at the record nearest to `iStop`, or at the last one."""
+    centres = np.asarray(vtime_mod)
+    half = dt / 2
+    if not (iMdA - half <= iSdA <= iMdB - half):
         raise ValueError("PROBLEM: time in the seeding file (%d) is outside of what model spans!" % iSdA)
-    kt0 = int(np.argmin(np.abs(vtime_mod[:] - iSdA)))
-    if iSdA >= vtime_mod[kt0]:
-        kt0 += 1
-    itM0 = vtime_mod[kt0]
-    if iStop:
-        ktN = int(np.argmin(np.abs(vtime_mod[:] - iStop)))
-    else:
-        ktN = len(vtime_mod) - 1
-    itMN = vtime_mod[ktN]
-    Nt = ktN - kt0 + 1
+    first = int(np.abs(centres - iSdA).argmin())
+    if centres[first] <= iSdA:
+        first += 1
+    last = int(np.abs(centres - iStop).argmin()) if iStop else len(centres) - 1
     if iverbose > 0:
-        print('    * [GetTimeSpan]: records %d..%d => %d model records' % (kt0, ktN, Nt))
-    return Nt, kt0, ktN, itM0, itMN
+        print('    * [GetTimeSpan]: records %d..%d => %d model records' % (first, last, last - first + 1))
+    return last - first + 1, first, last, centres[first], centres[last]
 
 
 def SeedInit(pIDs, pSG, pSC, platT, plonT, pYf, pXf, pResolKM, maskT, xIceConc=[], iverbose=0, ctx=None):
