@@ -735,7 +735,7 @@ SITRK_API int sitrk_step(sitrk_t *h, int slot, int jrec)
 template <typename FT>
 static void launch_run(sitrk_ctx *h, const RunArgs &ra)
 {
-    dim3 grid(nblocks(ra.s.nP)), block(kBlock);
+    dim3 grid(nblocks(ra.s.nP, kRunBlock)), block(kRunBlock);
     // dynamic LDS: tables + the patch's F-points
     const size_t lds = kRunLdsFixed + (size_t)ra.patch_cells * sizeof(pt);
 #define SITRK_LAUNCH_RUN(KERNEL)                                                                          \

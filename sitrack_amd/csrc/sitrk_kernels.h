@@ -593,11 +593,15 @@ __device__ __forceinline__ void resolve_crossing_lds(pt P1, pt P2, pt bl, pt br,
 
 static constexpr int kRunLdsFixed = 256 + 128 + 64;      // crossing table, its LDS-offset twin, bounding box / patch header
 
+#ifndef SITRK_RUN_BLOCK
+#define SITRK_RUN_BLOCK 256             // workgroup size of the fused kernel (A/B: tools/build_variant.sh x -DSITRK_RUN_BLOCK=128 ...)
+#endif
+static constexpr int kRunBlock = SITRK_RUN_BLOCK;
 #ifndef SITRK_RUN_WAVES
 #define SITRK_RUN_WAVES 6               // <= 80 VGPRs (28 B of scratch): 6 waves per SIMD measured 7 % faster than 5 without spills,
 #endif                                  // 7 waves (72 VGPRs, 44 B) 25 % slower
 template <typename FT, int UVS, bool WINDOW>
-__global__ __launch_bounds__(kBlock, SITRK_RUN_WAVES) void advect_run_kernel(RunArgs ra)
+__global__ __launch_bounds__(kRunBlock, SITRK_RUN_WAVES) void advect_run_kernel(RunArgs ra)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *s_tab = (int *)smem;                            // CrossTab, 64 ints
@@ -606,7 +610,7 @@ __global__ __launch_bounds__(kBlock, SITRK_RUN_WAVES) void advect_run_kernel(Run
     const StepArgs &a = ra.s;
     const unsigned blk = (a.tune & TUNE_XCD_REMAP) ? xcd_remap(blockIdx.x, gridDim.x)
                          : (ra.xcd_group > 1 ? xcd_group(blockIdx.x, gridDim.x, (unsigned)ra.xcd_group) : blockIdx.x);
-    const int64_t p = (int64_t)blk * kBlock + threadIdx.x;
+    const int64_t p = (int64_t)blk * kRunBlock + threadIdx.x;
     const bool nt = (a.tune & TUNE_NT_STATE) != 0;
     int32_t c = -1;
     if (p < a.nP) c = nt ? __builtin_nontemporal_load(&a.cell[p]) : a.cell[p];
@@ -654,7 +658,7 @@ __global__ __launch_bounds__(kBlock, SITRK_RUN_WAVES) void advect_run_kernel(Run
     if (pa.PR > 3) {
         // a row of the patch is contiguous in the F-only copy of the geometry
         const int ncell = pa.PR * pa.PC;
-        for (int t = threadIdx.x; t < ncell; t += kBlock) {
+        for (int t = threadIdx.x; t < ncell; t += kRunBlock) {
             const int r = t / pa.PC, cc = t - r * pa.PC;
             *(v2d *)(s_geo + (size_t)t * sizeof(pt)) = *(const v2d *)(ra.geoF + ((size_t)(pa.R0 + r) * a.Ni + pa.C0 + cc));
         }
@@ -745,7 +749,7 @@ __global__ __launch_bounds__(kBlock, SITRK_RUN_WAVES) void advect_run_kernel(Run
             c |= SITRK_DEAD_BIT;
             unsigned tk = threadIdx.x;
             asm volatile("" : "+v"(tk));
-            a.kill_rec[(int64_t)blk * kBlock + tk] = jrec;
+            a.kill_rec[(int64_t)blk * kRunBlock + tk] = jrec;
             break;                                       // dead buoys never step again
         }
     }
@@ -753,7 +757,7 @@ __global__ __launch_bounds__(kBlock, SITRK_RUN_WAVES) void advect_run_kernel(Run
     // scratch across the loop, i.e. written and read back through HBM)
     unsigned tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
-    const int64_t pe = (int64_t)blk * kBlock + tid;
+    const int64_t pe = (int64_t)blk * kRunBlock + tid;
     if (moved) {
         if (nt) store_pt_nt(&a.pos[pe], P);
         else a.pos[pe] = P;
