@@ -58,7 +58,9 @@ def one_case(rng, idx, nstrat=2):
     fuse = int(rng.choice([1, 2, 8, 32]))
     tile = int(rng.choice([0, 8 * 256 + 16, 4 * 256 + 4, 32 * 256 + 32]))
     trk.ctx.set_tuning(fuse=fuse, sort_tile=tile, nt_state=int(rng.integers(0, 2)), xcd_remap=int(rng.integers(0, 2)),
-                       step_block=int(rng.choice([256, 512, 1024])))
+                       step_block=int(rng.choice([256, 512, 1024])),
+                       patch_kb=int(rng.choice([0, 2, 16, 40])), patch_margin=int(rng.choice([0, 2, 8])),
+                       xcd_group=int(rng.choice([0, 3, 16])))
     trk.set_buoys(yx, ji, first, last, sort=bool(rng.random() < 0.8))
     trk.ctx.set_resort(int(rng.choice([0, 3, 17])))
     g2 = dict(grid); g2["tmask"] = tmask
