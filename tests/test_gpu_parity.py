@@ -533,7 +533,10 @@ def test_tuning_knobs_do_not_change_results():
     _, yx = syn.make_buoys(grid, 30011, seed=21, frac=0.7)
     res = []
     for knobs in ({}, {"xcd_remap": 1}, {"nt_state": 1}, {"xcd_remap": 1, "nt_state": 1}, {"sort_tile": 8 * 256 + 32},
-                  {"sort_tile": 5 * 256 + 7, "nt_state": 1, "xcd_remap": 1}):
+                  {"sort_tile": 5 * 256 + 7, "nt_state": 1, "xcd_remap": 1},
+                  # the fused kernel's LDS patch: none, tiny (most buoys leave it: global fallback), large; XCD grouping; one-record launches
+                  {"patch_kb": 0}, {"patch_kb": 1, "patch_margin": 0}, {"patch_kb": 60, "patch_margin": 40}, {"xcd_group": 0},
+                  {"xcd_group": 5, "patch_kb": 3}, {"fuse": 1}, {"fuse": 2, "patch_kb": 2}):
         trk = make_tracker(grid, grid["tmask"], 3)
         found, ji, _ = sit.FindContainingCell(yx, syn.nearest_t_plane(grid, yx), ctx=trk.ctx)
         trk.ctx.set_tuning(**knobs)
