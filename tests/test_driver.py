@@ -79,6 +79,24 @@ def test_longitudes_wrap_in_the_stored_dtype():
     assert np.array_equal(ncio._lon360(np.array([-9999., -10.], dtype='f4'), fill=-9999.), [-9999., 350.])
 
 
+def test_seed_cache_writer_is_a_plain_npz(tmp_path):
+    """The seed cache (reference si3_part_tracker.py:255: np.savez_compressed) is written by an own ZIP64 writer that deflates
+    4-MB pieces on a thread pool: `np.load` and zipfile's CRC check must take it like any .npz -- scalars stay 0-d,
+    empty and non-contiguous arrays, members longer than one piece."""
+    import zipfile
+    rng = np.random.default_rng(2)
+    n = 700_001                                                   # xPosG0: 11 MB = three pieces
+    arrs = dict(nP=n, xPosG0=rng.random((n, 2)), IDs=np.arange(n) * 7 + 300534062025510, VRTCS=rng.integers(0, 500, (1000, 2, 4)),
+                empty=np.zeros((0, 2)), strided=np.arange(20).reshape(4, 5)[:, ::2], one=np.float32(1.5))
+    f = str(tmp_path / "Initialized_buoys_x.npz")
+    drv._savez_deflate(f, **arrs)
+    with np.load(f) as z:
+        assert sorted(z.files) == sorted(arrs)
+        for k, v in arrs.items():
+            assert np.array_equal(z[k], v) and z[k].dtype == np.asarray(v).dtype and z[k].shape == np.shape(v), k
+    assert zipfile.ZipFile(f).testzip() is None
+
+
 def test_record_windows_skip_masked_time_positions():
     base = 850608000
     vt = (base + 1800 + 3600 * np.arange(24)).astype('i4')
