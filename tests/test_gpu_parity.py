@@ -206,6 +206,32 @@ def test_rim_cells_and_negative_index_wrap():
     assert np.array_equal(st["vJIt"], ref.jiT) and np.array_equal(st["iAlive"], ref.alive)
     assert (ref.alive == 0).sum() > 10 and ref.jiT.min() == 0
     trk.close()
+    # The fused entry point never lets such a buoy set into advect_run_kernel (its table-driven crossing path has no
+    # negative-index wrap): sitrk_run steps it record by record -- same answers, and the launch statistics say so.  A set
+    # that starts two cells off the rim does go through the fused kernel, and buoys that walk into row/column 1 die there.
+    for inner in (False, True):
+        trk = make_tracker(grid, tmask, 4)
+        if inner:
+            jj = np.array([[2, i] for i in range(2, Ni - 2)] + [[j, 2] for j in range(3, Nj - 2)], dtype=np.int64)
+            yy = np.stack([grid["Yt"][jj[:, 0], jj[:, 1]], grid["Xt"][jj[:, 0], jj[:, 1]]], axis=1)
+            found, jj2, _ = sit.FindContainingCell(yy, jj, ctx=trk.ctx)
+            yy, jj = yy[found & np.all(jj2 == jj, axis=1)], jj[found & np.all(jj2 == jj, axis=1)]
+        else:
+            yy, jj = yx, ji
+        for k in range(4):
+            trk.load_record(k, u[0], v[0], sic[0])
+        trk.set_buoys(yy, jj)
+        ref = orc.Tracker(g2, yy, jj)
+        trk.ctx.launch_stats(reset=True)
+        trk.ctx.run(0, 0, 8)
+        for jrec in range(8):
+            ref.step(jrec, u[0], v[0], sic[0], want_out=False)
+        st = trk.state()
+        assert np.array_equal(st["yx"], ref.pos) and np.array_equal(st["vJIt"], ref.jiT) and np.array_equal(st["iAlive"], ref.alive)
+        ls = trk.ctx.launch_stats()
+        assert (ls["fused_launches"] > 0) == inner and (ls["step_launches"] == 8) == (not inner), ls
+        assert (ref.alive == 0).sum() > 5
+        trk.close()
 
 
 def _step_ulps(x, k):
