@@ -473,10 +473,15 @@ def main():
         dt = time.perf_counter() - t0
         ctx.set_stream(None)
         e2e_bytes_per_step = band["bytes"] / float(a.warmup + a.steps)
-    if dist is not None:
-        t = torch.tensor([dt, ev_ms], dtype=torch.float64, device=red_dev)
+    if dist is not None:                                 # the slowest rank sets every reported time
+        extra = [per_record[0], per_record[1]] if per_record is not None else [0.0, 0.0]
+        t = torch.tensor([dt, ev_ms] + extra + [eight or 0.0], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, ev_ms = float(t[0]), float(t[1])
+        if per_record is not None:
+            per_record = (float(t[2]), float(t[3]), per_record[2])
+        if eight is not None:
+            eight = float(t[4])
 
     nalive = ctx.count_alive()
     if dist is not None:
@@ -487,6 +492,21 @@ def main():
     if a.check and rank == 0:
         nchk = a.warmup + a.steps * (1 + (per_record is not None) + (eight is not None))
         cpu_baseline_check(ctx, grid, u, v, sic, yx, ji, nchk, a.uv_strategy)
+
+    def measured_copy_GBps():
+        """practical HBM ceiling of this GPU, measured now: a device-to-device copy of 1 GiB (read + write bytes / time)"""
+        try:
+            n = 1 << 28
+            x = torch.empty(n, dtype=torch.float32, device="cuda"); y = torch.empty_like(x)
+            y.copy_(x); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                y.copy_(x)
+            e1.record(); torch.cuda.synchronize()
+            return 5 * 2 * 4.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        except Exception:                                          # noqa: BLE001
+            return None
 
     e2e_bcast = None
     if dist is not None and a.regime == "resident" and backend == "nccl" and not a.no_e2e_broadcast:
@@ -578,6 +598,11 @@ def main():
             line["per_record_launch"] = {
                 "value": total / dt1, "ms_per_step": 1e3 * dt1 / a.steps, "kernel": "advect_step_kernel",
                 "launches": st1["step_launches"], "roofline": roofline_step(ev1 / max(st1["step_launches"], 1))}
+            cp = measured_copy_GBps()
+            if cp:
+                rr = line["per_record_launch"]["roofline"]
+                rr["device_copy_GBps_measured"] = cp                 # the practical ceiling next to the 8 TB/s spec
+                rr["frac_of_measured_copy"] = rr["achieved"] / cp
         if eight is not None:
             line["eight_records_per_launch"] = {"value": total / eight, "ms_per_step": 1e3 * eight / a.steps,
                                                 "note": "same kernel, 8 records per launch (SURVEY 8d keeps K = 8 records resident)"}

@@ -3,10 +3,10 @@
 // The hot path is advance_record(): everything one buoy does for one model record, one buoy per
 // lane.  Buoys are kept sorted by host cell (tile-major), so a wavefront's gathers fall on a few
 // contiguous 48-byte cell records (F,U,V plane coordinates interleaved) and short runs of the u/v
-// slabs; L1/L2 coalesce them, there is no cross-lane reuse left for LDS to exploit, and nothing is a
-// contraction (no MFMA).  Two launch forms:
-//   advect_step_kernel : one record per launch  -- HBM bound (~84 B and ~250 fp64-issue slots per particle-step)
-//   advect_run_kernel  : up to 32 resident records per launch, buoy and cell context in registers -- issue bound
+// slabs, which L1/L2 coalesce; nothing is a contraction (no MFMA).  Two launch forms:
+//   advect_step_kernel : one record per launch  -- HBM bound (~84 B per particle-step, 0.62 of the 8 TB/s spec)
+//   advect_run_kernel  : up to 32 resident records per launch; buoy and cell context in registers, the workgroup's
+//                        F-points in LDS, crossing path driven by a table in LDS -- fp64 VALU-issue bound (86 % busy)
 // Measurements and the optimisation history are in DESIGN.md section 3.2.
 #pragma once
 #include "sitrk_internal.h"
@@ -272,8 +272,9 @@ __device__ __forceinline__ pt geo_pt(const char *__restrict__ gb, unsigned off, 
     return *(const pt *)(gb + (size_t)off + (ptrdiff_t)imm);
 }
 
-// P1 -> P2 leaves the cell whose quad is (bl, br, ur, ul); k48 = byte offset of the cell's geometry record, k9 = the 3x3
-// Survive word of the cell for this record.  Returns the crossed edge kc (1..4) and fills the increments of the destination cell; `killed` = its Survive byte.
+// P1 -> P2 leaves the cell whose quad is (bl, br, ur, ul); k48 = byte offset of the cell's geometry record, k9 = the
+// Survive bits of the cell's 8 neighbours for this record (pack_kill9_kernel).  Returns the crossed edge kc (1..4) and
+// fills the increments of the destination cell; `killed` = the destination's Survive byte.
 // Same predicates on the same operands in the same order as resolve_crossing().
 __device__ __forceinline__ int resolve_crossing_tab(pt P1, pt P2, pt bl, pt br, pt ur, pt ul, unsigned k48, unsigned k9,
                                                     const char *__restrict__ gb,
@@ -696,7 +697,7 @@ __global__ __launch_bounds__(kRunBlock, SITRK_RUN_WAVES) void advect_run_kernel(
         // the four velocity candidates u[jT,iT-1], u[jT,iT], v[jT-1,iT], v[jT,iT]
         FT fu0 = *(const FT *)(ub + x.o1 - sizeof(FT)), fu1 = *(const FT *)(ub + x.o1);
         FT fv0 = *(const FT *)(vb + x.o0), fv1 = *(const FT *)(vb + x.o1);
-        // ... and the cell's 3x3 Survive word of this record (used only if the buoy leaves the cell)
+        // ... and the Survive byte of the cell's 8 neighbours for this record (used only if the buoy leaves the cell)
         unsigned k9 = *(const uint8_t *)(kb + (x.o1 >> (sizeof(FT) == 4 ? 2 : 3)));
         double zU, zV;
         if (UVS == 0) {                                  // :423-425
