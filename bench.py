@@ -372,9 +372,9 @@ def main():
             nrun += a.steps
         ctx.set_tuning(fuse=fuse)
     elif a.e2e_library:
-        # end-to-end through the library's own ingest (sitrk_stage_acquire / sitrk_stage_submit): every record is copied
-        # by this host thread into the library's pinned staging -- the part a NetCDF reader plays in the driver -- and
-        # travels on the library's copy stream while the previous record is stepped with.  One GPU only.
+        # end-to-end through the library's own ingest (sitrk_push_record_rows): every record is copied from ordinary host
+        # arrays into the library's pinned staging (the part a NetCDF reader plays in the driver, which reads into the
+        # staging directly) and travels on the library's copy stream while the previous record is stepped with.  One GPU only.
         fuse = 1
         assert world == 1 and K >= 2
         band = {"eval": -10**9, "jmin": 0, "jmax": Nj - 1, "bytes": 0}
@@ -386,9 +386,8 @@ def main():
                 age = sidx - band["eval"]
                 j0, j1 = max(0, band["jmin"] - 2 - age), min(Nj, band["jmax"] + 3 + age)
             band["bytes"] += 3 * (j1 - j0) * Ni * 4
-            bu, bv, bs = ctx.stage(j1 - j0)
-            bu[...] = u[sidx % K][j0:j1]; bv[...] = v[sidx % K][j0:j1]; bs[...] = sic[sidx % K][j0:j1]
-            ctx.submit(sidx % 2, j0)
+            k = sidx % K                                         # host arrays -> the library's pinned staging -> copy stream
+            ctx.push_record_rows(sidx % 2, j0, j1, u[k][j0:j1], v[k][j0:j1], sic[k][j0:j1])
 
         def run_e2e(s0, n):
             for sidx in range(s0, s0 + n):

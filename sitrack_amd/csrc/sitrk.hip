@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/sitrk.h"
@@ -443,7 +444,29 @@ static int push_rows(sitrk_ctx *h, int slot, int j0, int j1, const void *u, cons
     int rc = sitrk_stage_acquire(h, j1 - j0, &su, &sv, &ss);
     if (rc) return rc;
     const size_t nb = (size_t)(j1 - j0) * h->Ni * elem_size(h->dtype);
-    memcpy(su, u, nb); memcpy(sv, v, nb); memcpy(ss, sic, nb);      // from here on the caller's buffers are its own again
+    // from here on the caller's buffers are its own again.  One thread copies ~10 GB/s into pinned memory, a fifth of what
+    // the PCIe link then moves: large records are copied by a few threads (201 MB at 4096^2: 20 ms -> 6 ms)
+    const void *src[3] = {u, v, sic};
+    void *dst[3] = {su, sv, ss};
+    const int nthr = nb >= ((size_t)8 << 20) ? 4 : 1;
+    if (nthr == 1) {
+        for (int f = 0; f < 3; f++) memcpy(dst[f], src[f], nb);
+    } else {
+        const size_t part = (nb + nthr - 1) / nthr;
+        auto copy_part = [=](int t) {
+            const size_t o = (size_t)t * part, n = o < nb ? std::min(part, nb - o) : 0;
+            for (int f = 0; f < 3 && n; f++) memcpy((char *)dst[f] + o, (const char *)src[f] + o, n);
+        };
+        std::thread pool[3];
+        int started = 0;
+        try {
+            for (; started < nthr - 1; started++) pool[started] = std::thread(copy_part, started + 1);
+        } catch (...) {                                 // no more threads to be had (no C++ exception crosses the C ABI)
+        }
+        copy_part(0);
+        for (int t = started; t < nthr - 1; t++) copy_part(t + 1);       // the parts nobody took
+        for (int t = 0; t < started; t++) pool[t].join();
+    }
     return sitrk_stage_submit(h, slot, j0, j1);
 }
 
