@@ -755,6 +755,13 @@ SITRK_API int sitrk_step(sitrk_t *h, int slot, int jrec)
     return SITRK_OK;
 }
 
+// div1000_of_f32's premise on the time step (sitrk_geom.h); outside it every lane takes the division
+static int f32_class_for(double rdt)
+{
+    const double ar = std::fabs(rdt);
+    return (ar >= 0x1p-700 && ar <= 0x1p700) ? kClassFiniteNonzeroF32 : 0;
+}
+
 template <typename FT>
 static void launch_run(sitrk_ctx *h, const RunArgs &ra)
 {
@@ -818,6 +825,7 @@ SITRK_API int sitrk_run(sitrk_t *h, int slot0, int jrec0, int nsteps)
         ra.patch_cells = (int)((size_t)h->patch_kb * 1024 / sizeof(pt));
         ra.patch_margin = h->patch_margin;
         ra.xcd_group = h->xcd_group;
+        ra.f32_class = f32_class_for(h->rdt);
         int used[kMaxFuse];
         for (int r = 0; r < m; r++) {
             const int slot = (slot0 + k + r) % h->nslots;
@@ -1178,7 +1186,7 @@ SITRK_API int sitrk_eval_euler(sitrk_t *h, int64_t n, const double *r, const dou
     HIPCHK(hipMemcpyAsync(s, r, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(s + b, vel, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(eval_euler_kernel, dim3(nblocks(n)), dim3(kBlock), 0, h->stream, n, (const double *)s, (const double *)(s + b),
-                       rdt, (double *)(s + 2 * b));
+                       rdt, f32_class_for(rdt), (double *)(s + 2 * b));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, s + 2 * b, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));

@@ -90,19 +90,36 @@ __device__ __forceinline__ bool inside_quad(double y, double x, pt q0, pt q1, pt
 // x/1000 = X 2^e / (8 * 125) is never closer than 2^-61 |v| to a midpoint of two doubles (125 (2M+1) is odd, X 2^g is
 // even) -> the rounding lands where RN(v) does.  Needs no over/underflow in q, r: guaranteed for 2^-900 <= |x| < 2^900;
 // everything else (zeros with their sign, subnormals, huge values, inf, NaN) takes the division.
-__device__ __forceinline__ double div1000(double x)
+// `k` is the constant 1000.: the fused loop hands it over in a scalar register pair (as a literal the compiler needs a
+// register copy of x in front of the fma).
+__device__ __forceinline__ double div1000_core(double x, double k, bool in_range)
 {
     const double z = 0x1.0624dd2f1a9fcp-10;                       // RN(1/1000)
-    const unsigned e = ((unsigned)__double2hiint(x) >> 20) & 0x7ffu;
     const double q = x * z;
-    const double r = __builtin_fma(-q, 1000., x);
+    const double r = __builtin_fma(-q, k, x);
     double f = __builtin_fma(r, z, q);
-    if (__builtin_expect(!((e - 123u) < 1800u), 0)) {
+    if (__builtin_expect(!in_range, 0)) {
         double t = x;
         asm volatile("" : "+v"(t));                               // keeps the division in a branch of its own (not if-converted)
         f = t / 1000.;
     }
     return f;
+}
+
+__device__ __forceinline__ double div1000(double x, double k = 1000.)
+{
+    const unsigned e = ((unsigned)__double2hiint(x) >> 20) & 0x7ffu;
+    return div1000_core(x, k, (e - 123u) < 1800u);
+}
+
+// x = RN((double)src * rdt) with `src` a binary32 value and 2^-700 <= |rdt| <= 2^700 (checked by the host, which hands over
+// class_mask = 0 otherwise: every lane then takes the division): x lies in [2^-900, 2^900) exactly when src is finite and
+// not zero (2^-149 <= |src| < 2^128), i.e. when v_cmp_class says normal or subnormal -- one instruction on the value as
+// loaded instead of three on the product's exponent.
+static constexpr int kClassFiniteNonzeroF32 = 0x008 | 0x010 | 0x080 | 0x100;   // -normal, -subnormal, +subnormal, +normal
+__device__ __forceinline__ double div1000_of_f32(double x, float src, int class_mask, double k)
+{
+    return div1000_core(x, k, __builtin_amdgcn_classf(src, class_mask));
 }
 
 // IsInsideQuadrangle without the divisions.  Per edge A->B the reference toggles when
@@ -126,6 +143,7 @@ __device__ __forceinline__ bool inside_quad_hot(double y, double x, pt q0, pt q1
     const bool g0 = y > q0.y, g1 = y > q1.y, g2 = y > q2.y, g3 = y > q3.y;
     const bool l0 = x <= q0.x, l1 = x <= q1.x, l2 = x <= q2.x, l3 = x <= q3.x;
     bool inside = false, decided = true;                 // logical operators: the predicates stay lane masks
+    // (the bookkeeping in bitwise form: lane masks combined by a handful of scalar instructions, no nested exec region)
 #define SITRK_EDGE(A, B, gA, gB, lA, lB)                                              \
     if ((gA != gB) && (lA || lB)) {                                                   \
         double c = B.y - A.y;                                                         \
@@ -133,8 +151,9 @@ __device__ __forceinline__ bool inside_quad_hot(double y, double x, pt q0, pt q1
         const double p = (y - A.y) * (B.x - A.x);                                     \
         const double E = __builtin_fma(x - A.x, c, -p);                               \
         const bool dec = fabs(E) > __builtin_fma(fabs(c), mx, 0x1p-1000);             \
-        decided = decided && dec;                                                     \
-        inside = inside != (dec && ((__double2hiint(E) < 0) == gA));                  \
+        const bool neg = __double2hiint(E) < 0;                                       \
+        decided = decided & dec;                                                      \
+        inside = inside != (dec & (neg == gA));                                       \
     }
     SITRK_EDGE(q0, q1, g0, g1, l0, l1)
     SITRK_EDGE(q1, q2, g1, g2, l1, l2)

@@ -232,7 +232,7 @@ __device__ __forceinline__ int32_t resolve_crossing(pt P1, pt P2, pt bl, pt br, 
 //   row kc-1:  [0] va  [1] vb  [2] eA  [3] eB   byte offsets into `geo` relative to the host cell's record
 //              [4] S   [5] A   [6] B            packed-cell increments (dj << 16) + di   straight / first / second diagonal
 //              [7] S   [8] A   [9] B            cell-index increments dj*Ni + di
-//              [10] S  [11] A  [12] B           bit of the neighbours' Survive byte (pack_kill9_kernel)
+//              [10] S  [11] A  [12] B           mask (1 << bit) of the destination in the neighbours' Survive byte (pack_kill9_kernel)
 // ---------------------------------------------------------------------------
 struct CrossTab { int v[4][16]; };
 
@@ -261,7 +261,7 @@ __host__ inline void make_cross_tab(int Ni, CrossTab &t, int (*dji)[7][2] = null
             r[4 + q] = dj * 65536 + di;
             r[7 + q] = dj * Ni + di;
             const int b9 = (dj + 1) * 3 + (di + 1);
-            r[10 + q] = b9 < 4 ? b9 : b9 - 1;
+            r[10 + q] = 1 << (b9 < 4 ? b9 : b9 - 1);
         }
     }
 }
@@ -285,8 +285,9 @@ __device__ __forceinline__ int resolve_crossing_tab(pt P1, pt P2, pt bl, pt br, 
     const bool h1 = (ccw(P1, bl, br) != ccw(P2, bl, br)) && (sbl != sbr);
     const bool h2 = (ccw(P1, br, ur) != ccw(P2, br, ur)) && (sbr != sur);
     const bool h3 = (ccw(P1, ur, ul) != ccw(P2, ur, ul)) && (sur != sul);
-    const int kc = h1 ? 1 : (h2 ? 2 : (h3 ? 3 : 4));
-    const int *row = tab + 16 * (kc - 1);
+    const unsigned ro = h1 ? 0u : (h2 ? 64u : (h3 ? 128u : 192u));            // byte offset of row kc-1 (selected as such)
+    const int kc = (int)(ro >> 6) + 1;                                       // (only the probes look at it)
+    const int *row = (const int *)((const char *)tab + ro);
     const int4 r0 = *(const int4 *)(row), r1 = *(const int4 *)(row + 4), r2 = *(const int4 *)(row + 8);
     const int bB = row[12];
     // one batch of independent loads: the crossed edge's two ends and the two extension points
@@ -307,8 +308,8 @@ __device__ __forceinline__ int resolve_crossing_tab(pt P1, pt P2, pt bl, pt br, 
     // UpdtInd4NewCell (:257-300); first match wins (if / elif)
     dcell = hitA ? r1.y : (hitB ? r1.z : r1.x);
     dk = hitA ? r2.x : (hitB ? r2.y : r1.w);
-    const int bit = hitA ? r2.w : (hitB ? bB : r2.z);
-    killed = ((k9 >> bit) & 1u) != 0;                                        // Survive (:483-484)
+    const int msk = hitA ? r2.w : (hitB ? bB : r2.z);
+    killed = (k9 & (unsigned)msk) != 0;                                      // Survive (:483-484)
     if (codes) {
         const int cA = (kc == 1) ? 5 : (kc == 2) ? 6 : 8, cB = (kc == 1) ? 6 : (kc == 4) ? 5 : 7;
         codes[0] = kc;
@@ -355,10 +356,10 @@ __device__ __forceinline__ unsigned xcd_group(unsigned bid, unsigned nwg, unsign
 // bound by memory latency, not by issue, and was measured 4-6 % SLOWER with them (and with pinned loads): it keeps
 // the plain forms.  `make EXACTDIV=1` builds the plain forms everywhere for A/B timing.
 #ifdef SITRK_EXACT_DIV
-#define SITRK_DIV1000(x) ((x) / 1000.)
+#define SITRK_DIV1000(x, ...) ((x) / 1000.)
 #define SITRK_INSIDE(y, x, q0, q1, q2, q3, eps) inside_quad(y, x, q0, q1, q2, q3)
 #else
-#define SITRK_DIV1000(x) div1000(x)
+#define SITRK_DIV1000(x, ...) div1000(x, ##__VA_ARGS__)
 #define SITRK_INSIDE(y, x, q0, q1, q2, q3, eps) inside_quad_hot(y, x, q0, q1, q2, q3, eps)
 #endif
 
@@ -482,6 +483,8 @@ struct RunArgs {
     int dji[4][7][2];                   // its (dj,di) pairs: va, vb, eA, eB, S, A, B per crossed edge (for the patch's own offsets)
     int patch_cells, patch_margin;      // LDS patch: capacity in cells (0 = no patch) and the largest margin to try
     int xcd_group;                      // > 1: runs of that many consecutive workgroups share an XCD
+    int f32_class;                      // v_cmp_class mask of div1000_of_f32: finite and non-zero, or 0 when |rdt| is outside
+                                        // [2^-700, 2^700] (every lane then divides)
 };
 
 // ---------------------------------------------------------------------------
@@ -543,12 +546,21 @@ __device__ __forceinline__ bool patch_covers(const Patch &pa, int jr, int ir)
     return (unsigned)(jr - 2) < (unsigned)(pa.PR - 3) && (unsigned)(ir - 2) < (unsigned)(pa.PC - 3);
 }
 
-__device__ __forceinline__ pt lds_pt(const char *s_geo, unsigned off, int imm = 0) { return *(const pt *)(s_geo + off + imm); }
+// A patch point by its LDS ADDRESS (32 bits, less kLdsBias so that the immediates -16 .. stay non-negative and fold into
+// the instruction's offset field): `la` already contains the patch's base -- no address arithmetic per access
+static constexpr int kLdsBias = 64;
+typedef __attribute__((address_space(3))) const v2d lds_cv2d;
+__device__ __forceinline__ pt lds_pt_at(unsigned address)
+{
+    const v2d t = *(lds_cv2d *)(uintptr_t)address;       // one ds_read_b128; members in the order of struct pt (y, x)
+    return make_pt(t.x, t.y);
+}
+__device__ __forceinline__ pt lds_pt(unsigned la, int imm = 0) { return lds_pt_at(la + (unsigned)(imm + kLdsBias)); }
 
-// the context of cell `kcell`: its quad from the patch (LDS offset lo of its own F-point), the U/V points and the
+// the context of cell `kcell`: its quad from the patch (biased LDS address lo of its own F-point), the U/V points and the
 // orientation byte from global memory
 template <unsigned ES>
-__device__ __forceinline__ void load_ctx_lds(const StepArgs &a, const Patch &pa, const char *s_geo, const char *__restrict__ gb,
+__device__ __forceinline__ void load_ctx_lds(const StepArgs &a, const Patch &pa, const char *__restrict__ gb,
                                              unsigned kcell, unsigned lo, CellCtx &x)
 {
     const unsigned Ni = (unsigned)a.Ni;
@@ -557,14 +569,14 @@ __device__ __forceinline__ void load_ctx_lds(const StepArgs &a, const Patch &pa,
     x.U11 = geo_pt(gb, k48, 16); x.V11 = geo_pt(gb, k48, 32); x.U10 = geo_pt(gb, k48, -32); x.V01 = geo_pt(gb, k48b, 32);
     x.ori = (unsigned)(uint8_t)a.orient[kcell];
     const unsigned lob = lo - (unsigned)pa.PC * (unsigned)sizeof(pt);
-    x.F11 = lds_pt(s_geo, lo, 0); x.F10 = lds_pt(s_geo, lo, -16);
-    x.F01 = lds_pt(s_geo, lob, 0); x.F00 = lds_pt(s_geo, lob, -16);
+    x.F11 = lds_pt(lo, 0); x.F10 = lds_pt(lo, -16);
+    x.F01 = lds_pt(lob, 0); x.F00 = lds_pt(lob, -16);
 }
 
 // resolve_crossing_tab() with every point read from the patch: same predicates, same operands, same order.
-// tabL row kc-1: [0] va [1] vb [2] eA [3] eB  LDS byte offsets relative to the host cell's record; [4] S [5] A [6] B
-// LDS byte increments to the destination cell's record
-__device__ __forceinline__ void resolve_crossing_lds(pt P1, pt P2, pt bl, pt br, pt ur, pt ul, unsigned lo, unsigned k9, const char *s_geo,
+// tabL row kc-1 (16 ints like a row of tab): [0] va [1] vb [2] eA [3] eB  LDS byte offsets relative to the host cell's
+// biased address (i.e. + kLdsBias); [4] S [5] A [6] B  LDS byte increments to the destination cell's record
+__device__ __forceinline__ void resolve_crossing_lds(pt P1, pt P2, pt bl, pt br, pt ur, pt ul, unsigned lo, unsigned k9,
                                                      const int *__restrict__ tab, const int *__restrict__ tabL, int &dcell, int &dk,
                                                      int &dlo, bool &killed)
 {
@@ -572,13 +584,13 @@ __device__ __forceinline__ void resolve_crossing_lds(pt P1, pt P2, pt bl, pt br,
     const bool h1 = (ccw(P1, bl, br) != ccw(P2, bl, br)) && (sbl != sbr);
     const bool h2 = (ccw(P1, br, ur) != ccw(P2, br, ur)) && (sbr != sur);
     const bool h3 = (ccw(P1, ur, ul) != ccw(P2, ur, ul)) && (sur != sul);
-    const int kc = h1 ? 1 : (h2 ? 2 : (h3 ? 3 : 4));
-    const int *row = tab + 16 * (kc - 1), *rowL = tabL + 8 * (kc - 1);
+    const unsigned ro = h1 ? 0u : (h2 ? 64u : (h3 ? 128u : 192u));            // both tables have 64-byte rows
+    const int *row = (const int *)((const char *)tab + ro), *rowL = (const int *)((const char *)tabL + ro);
     const int4 r1 = *(const int4 *)(row + 4), r2 = *(const int4 *)(row + 8);
     const int bB = row[12];
     const int4 l0 = *(const int4 *)(rowL), l1 = *(const int4 *)(rowL + 4);
-    const pt va = lds_pt(s_geo, lo + (unsigned)l0.x), vb = lds_pt(s_geo, lo + (unsigned)l0.y);
-    const pt eA = lds_pt(s_geo, lo + (unsigned)l0.z), eB = lds_pt(s_geo, lo + (unsigned)l0.w);
+    const pt va = lds_pt_at(lo + (unsigned)l0.x), vb = lds_pt_at(lo + (unsigned)l0.y);     // (the table's offsets carry the bias)
+    const pt eA = lds_pt_at(lo + (unsigned)l0.z), eB = lds_pt_at(lo + (unsigned)l0.w);
     bool hitA = ccw(P1, va, eA) != ccw(P2, va, eA);
     bool hitB = ccw(P1, vb, eB) != ccw(P2, vb, eB);
     if (hitA || hitB) {
@@ -588,11 +600,11 @@ __device__ __forceinline__ void resolve_crossing_lds(pt P1, pt P2, pt bl, pt br,
     dcell = hitA ? r1.y : (hitB ? r1.z : r1.x);
     dk = hitA ? r2.x : (hitB ? r2.y : r1.w);
     dlo = hitA ? l1.y : (hitB ? l1.z : l1.x);
-    const int bit = hitA ? r2.w : (hitB ? bB : r2.z);
-    killed = ((k9 >> bit) & 1u) != 0;
+    const int msk = hitA ? r2.w : (hitB ? bB : r2.z);
+    killed = (k9 & (unsigned)msk) != 0;
 }
 
-static constexpr int kRunLdsFixed = 256 + 128 + 64;      // crossing table, its LDS-offset twin, bounding box / patch header
+static constexpr int kRunLdsFixed = 256 + 256 + 64;      // crossing table, its LDS-offset twin (same row stride), bounding box / patch header
 
 #ifndef SITRK_RUN_BLOCK
 #define SITRK_RUN_BLOCK 256             // workgroup size of the fused kernel (A/B: tools/build_variant.sh x -DSITRK_RUN_BLOCK=128 ...)
@@ -606,8 +618,8 @@ __global__ __launch_bounds__(kRunBlock, SITRK_RUN_WAVES) void advect_run_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *s_tab = (int *)smem;                            // CrossTab, 64 ints
-    int *s_tabL = s_tab + 64;                            // 4 x 8 ints
-    int *s_box = s_tabL + 32;                            // [0..3] jmin jmax imin imax of the live buoys; [4..7] R0 C0 PR PC
+    int *s_tabL = s_tab + 64;                            // 4 rows of 16 ints (7 used)
+    int *s_box = s_tabL + 64;                            // [0..3] jmin jmax imin imax of the live buoys; [4..7] R0 C0 PR PC
     const StepArgs &a = ra.s;
     const unsigned blk = (a.tune & TUNE_XCD_REMAP) ? xcd_remap(blockIdx.x, gridDim.x)
                          : (ra.xcd_group > 1 ? xcd_group(blockIdx.x, gridDim.x, (unsigned)ra.xcd_group) : blockIdx.x);
@@ -653,7 +665,7 @@ __global__ __launch_bounds__(kRunBlock, SITRK_RUN_WAVES) void advect_run_kernel(
     if (threadIdx.x < 28) {
         // LDS twins of the table's geometry offsets: (dj*PC + di) * 16 for va, vb, eA, eB, S, A, B of each crossed edge
         const int e = threadIdx.x / 7, q = threadIdx.x % 7;
-        s_tabL[8 * e + q] = (ra.dji[e][q][0] * pa.PC + ra.dji[e][q][1]) * (int)sizeof(pt);
+        s_tabL[16 * e + q] = (ra.dji[e][q][0] * pa.PC + ra.dji[e][q][1]) * (int)sizeof(pt) + (q < 4 ? kLdsBias : 0);
     }
     const char *__restrict__ gb = (const char *)a.geo;
     if (pa.PR > 3) {
@@ -674,16 +686,19 @@ __global__ __launch_bounds__(kRunBlock, SITRK_RUN_WAVES) void advect_run_kernel(
     CellCtx x;
     // position of the host cell inside the patch, packed like the cell itself (jr << 16 | ir), and the LDS offset of its record
     int crel = c - ((pa.R0 << 16) | pa.C0);
-    unsigned lo = patch_off(pa, crel >> 16, crel & 0xffff);
+    const unsigned geo_la = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)s_geo - (unsigned)kLdsBias;
+    unsigned lo = geo_la + patch_off(pa, crel >> 16, crel & 0xffff);
     bool inl = patch_covers(pa, crel >> 16, crel & 0xffff);
     {
         const unsigned kcell = (unsigned)(cell_j(c) * a.Ni + cell_i(c));
-        if (inl) load_ctx_lds<sizeof(FT)>(a, pa, s_geo, gb, kcell, lo, x);
+        if (inl) load_ctx_lds<sizeof(FT)>(a, pa, gb, kcell, lo, x);
         else load_ctx<sizeof(FT)>(a, gb, kcell, x);
     }
     // the record pointers (scalar loads from the kernel arguments) are fetched one record ahead: a record's vector
     // loads go out at the top of its iteration instead of behind a scalar load and its wait (-0.7 %)
     const char *ub_next = (const char *)ra.u[0], *vb_next = (const char *)ra.v[0], *kb_next = (const char *)ra.kill9[0];
+    double k1000 = 1000.;                                // div1000's constant, kept in scalar registers
+    asm volatile("" : "+s"(k1000));
 #pragma unroll 1
     for (int r = 0; r < ra.nrec; r++) {
         const int jrec = a.jrec + r;
@@ -700,6 +715,7 @@ __global__ __launch_bounds__(kRunBlock, SITRK_RUN_WAVES) void advect_run_kernel(
         // ... and the Survive byte of the cell's 8 neighbours for this record (used only if the buoy leaves the cell)
         unsigned k9 = *(const uint8_t *)(kb + (x.o1 >> (sizeof(FT) == 4 ? 2 : 3)));
         double zU, zV;
+        FT su = 0, sv = 0;                               // UVS == 1: the selected candidates as loaded
         if (UVS == 0) {                                  // :423-425
             zU = 0.5 * ((double)fu1 + (double)fu0);
             zV = 0.5 * ((double)fv1 + (double)fv0);
@@ -713,14 +729,24 @@ __global__ __launch_bounds__(kRunBlock, SITRK_RUN_WAVES) void advect_run_kernel(
             const bool llum1 = (ccw(P, x.V01, x.V11) != sFV) && (ccw(P, x.F11, x.V01) != ccw(P, x.F11, x.V11));
             const bool llvm1 = (ccw(P, x.U10, x.U11) != sFU) && (ccw(P, x.F11, x.U10) != ccw(P, x.F11, x.U11));
             pin_load(fu0); pin_load(fv0);
-            zU = llum1 ? (double)fu0 : (double)fu1;
-            zV = llvm1 ? (double)fv0 : (double)fv1;
+            su = llum1 ? fu0 : fu1;
+            sv = llvm1 ? fv0 : fv1;
+            zU = (double)su;
+            zV = (double)sv;
         }
         const double dx = zU * a.rdt;                    // :452-458
         const double dy = zV * a.rdt;
         pt Pn;
-        Pn.x = P.x + SITRK_DIV1000(dx);
-        Pn.y = P.y + SITRK_DIV1000(dy);
+#ifndef SITRK_EXACT_DIV
+        if (UVS == 1 && sizeof(FT) == 4) {               // binary32 records: the range test of div1000 on the value as loaded
+            Pn.x = P.x + div1000_of_f32(dx, (float)su, ra.f32_class, k1000);
+            Pn.y = P.y + div1000_of_f32(dy, (float)sv, ra.f32_class, k1000);
+        } else
+#endif
+        {
+            Pn.x = P.x + SITRK_DIV1000(dx, k1000);
+            Pn.y = P.y + SITRK_DIV1000(dy, k1000);
+        }
         moved = true;
         bool killed = false;
         if (!SITRK_INSIDE(Pn.y, Pn.x, x.F00, x.F01, x.F11, x.F10, a.eps_mg)) {      // :466-484
@@ -728,7 +754,7 @@ __global__ __launch_bounds__(kRunBlock, SITRK_RUN_WAVES) void advect_run_kernel(
             int dcell, dk, dlo = 0;
             pin_load(k9);
             if (inl) {
-                resolve_crossing_lds(P, Pn, x.F00, x.F01, x.F11, x.F10, lo, k9, s_geo, s_tab, s_tabL, dcell, dk, dlo, killed);
+                resolve_crossing_lds(P, Pn, x.F00, x.F01, x.F11, x.F10, lo, k9, s_tab, s_tabL, dcell, dk, dlo, killed);
             } else {
                 resolve_crossing_tab(P, Pn, x.F00, x.F01, x.F11, x.F10, kcell * (unsigned)sizeof(CellGeo), k9, gb, s_tab, dcell, dk, killed);
             }
@@ -739,10 +765,10 @@ __global__ __launch_bounds__(kRunBlock, SITRK_RUN_WAVES) void advect_run_kernel(
             if (inl) {
                 lo += (unsigned)dlo;
             } else {
-                lo = patch_off(pa, crel >> 16, crel & 0xffff);
+                lo = geo_la + patch_off(pa, crel >> 16, crel & 0xffff);
             }
             inl = patch_covers(pa, crel >> 16, crel & 0xffff);
-            if (inl) load_ctx_lds<sizeof(FT)>(a, pa, s_geo, gb, kcell + (unsigned)dk, lo, x);
+            if (inl) load_ctx_lds<sizeof(FT)>(a, pa, gb, kcell + (unsigned)dk, lo, x);
             else load_ctx<sizeof(FT)>(a, gb, kcell + (unsigned)dk, x);
         }
         P = Pn;
@@ -837,14 +863,23 @@ __global__ void eval_inside_kernel(int64_t n, const pt *__restrict__ pts, const 
     out[k] = (hot ? 1 : 0) | (hot != ref ? 2 : 0);
 }
 
-// r + (vel * rdt) / 1000. as the hot loop evaluates it (si3_part_tracker.py:452-458)
-__global__ void eval_euler_kernel(int64_t n, const double *__restrict__ r, const double *__restrict__ vel, double rdt,
+// r + (vel * rdt) / 1000. as the hot loop evaluates it (si3_part_tracker.py:452-458): a velocity that is a binary32 value
+// (what a float32 record holds) goes the way the fused loop takes for such records, everything else the general way
+__global__ void eval_euler_kernel(int64_t n, const double *__restrict__ r, const double *__restrict__ vel, double rdt, int f32_class,
                                   double *__restrict__ out)
 {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    const double d = vel[k] * rdt;
-    out[k] = r[k] + SITRK_DIV1000(d);
+    const double w = vel[k];
+    const double d = w * rdt;
+    const float wf = (float)w;
+    double q = SITRK_DIV1000(d);
+#ifndef SITRK_EXACT_DIV
+    double k1000 = 1000.;
+    asm volatile("" : "+s"(k1000));
+    if ((double)wf == w) q = div1000_of_f32(d, wf, f32_class, k1000);
+#endif
+    out[k] = r[k] + q;
 }
 
 __global__ void eval_intersect_kernel(int64_t n, const pt *__restrict__ segs, int8_t *__restrict__ inter, int8_t *__restrict__ ccw_abc)

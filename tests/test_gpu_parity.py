@@ -296,9 +296,15 @@ def test_euler_update_without_division(ctx):
     special = np.array([0.0, -0.0, 5e-324, -5e-324, 1e-310, 2.0 ** -1022, 2.0 ** -905, 2.0 ** -912, 2.0 ** -911 * 1.7,
                         2.0 ** 888, 2.0 ** 889, -2.0 ** 1000, 1e300, 1.7e308, np.inf, -np.inf, np.nan, 1e20, 9.96921e36])
     vel[-special.size:] = special
+    # binary32 values take the fused loop's own range test (v_cmp_class on the value as loaded): zeros, subnormals, the
+    # largest and smallest normals, NetCDF's default fill, infinities
+    f32s = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-40, -3e-39, 1.1754944e-38, -1.1754944e-38, 3.4028235e38, -3.4028235e38,
+                     9.96921e36, 1e20, np.inf, -np.inf, np.nan, 0.3, -0.25], dtype=np.float32).astype(np.float64)
+    vel[-special.size - f32s.size:-special.size] = f32s
     r = rng.uniform(-5000, 5000, n)
-    r[-special.size:] = np.where(np.arange(special.size) % 2, -0.0, 0.0)          # keeps the sign of a zero quotient visible
-    for rdt in (3600., 1.0, 900.):
+    nsp = special.size + f32s.size
+    r[-nsp:] = np.where(np.arange(nsp) % 2, -0.0, 0.0)                            # keeps the sign of a zero quotient visible
+    for rdt in (3600., 1.0, 900., -3600., 2.0 ** -705, 2.0 ** 701, 2.0 ** -699, 2.0 ** 699):
         with np.errstate(all="ignore"):
             want = r + (vel * rdt) / 1000.
         got = ctx.eval_euler(r, vel, rdt)

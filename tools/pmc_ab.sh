@@ -19,8 +19,10 @@ for v in $VARS; do
   g=0
   for grp in "${GROUPS_[@]}"; do
     g=$((g+1))
+    # PMC_ONLY="1 2 10" restricts the passes to those groups
+    if [ -n "$PMC_ONLY" ] && ! echo " $PMC_ONLY " | grep -q " $g "; then continue; fi
     # (a counter group the hardware cannot collect aborts rocprofv3 and leaves the child hanging: bound every pass)
-    timeout -k 10 150 rocprofv3 --pmc $grp --output-format csv -d $OUT/${v}_g$g -- python3 bench.py --steps 64 --warmup 32 --no-cpu-baseline --no-c2 > $OUT/${v}_g$g.log 2>&1 || { echo "pmc pass $v g$g ($grp) failed"; grep -m2 "error code\|Error" $OUT/${v}_g$g.log; }
+    timeout -k 10 150 rocprofv3 --pmc $grp --output-format csv -d $OUT/${v}_g$g -- python3 bench.py --steps 64 --warmup 32 --no-cpu-baseline --no-c2 --only-fused > $OUT/${v}_g$g.log 2>&1 || { echo "pmc pass $v g$g ($grp) failed"; grep -m2 "error code\|Error" $OUT/${v}_g$g.log; }
     echo "$v g$g done"
   done
 done
