@@ -508,8 +508,26 @@ def main():
             return None
 
     e2e_bcast = None
+    e2e_hung = False
     if dist is not None and a.regime == "resident" and backend == "nccl" and not a.no_e2e_broadcast:
-        e2e_bcast = e2e_broadcast_segment(ctx, dist, torch, sd, rank, world, slabs_host, K, a.warmup + a.steps * 3, Nj, Ni)
+        # Everything `value` needs is measured and reduced by now.  The extra segment runs under a watchdog: if a collective
+        # in it never completes on some rank, every rank gives up after the same wait, rank 0 still prints the line (with
+        # the segment marked as timed out) and the processes leave without touching the stuck communicator.
+        import threading
+        box = {}
+
+        def _segment():
+            torch.cuda.set_device(dev)
+            box["out"] = e2e_broadcast_segment(ctx, dist, torch, sd, rank, world, slabs_host, K, a.warmup + a.steps * 3, Nj, Ni)
+
+        th = threading.Thread(target=_segment, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("SITRK_E2E_SEGMENT_TIMEOUT", "150")))
+        if th.is_alive():
+            e2e_hung = True
+            e2e_bcast = {"error": "timed out (a collective of the segment did not complete); the resident numbers above are unaffected"}
+        else:
+            e2e_bcast = box.get("out", {"error": "segment thread ended without a result"})
 
     if rank == 0:
         total = float(nP) * world * a.steps
@@ -611,7 +629,10 @@ def main():
             line["c2"] = c2_subrun(sit, syn, dev, a)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(grid, u, v, sic, yx, ji, a.cpu_seconds, a.uv_strategy)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
+    if e2e_hung:
+        sys.stderr.flush()
+        os._exit(0)                                     # a thread is stuck inside a collective: no orderly teardown possible
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

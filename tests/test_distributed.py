@@ -336,6 +336,22 @@ def test_bench_multi_gpu_code_path_with_one_rccl_rank():
 
 
 @pytest.mark.gpu
+def test_bench_line_survives_a_stuck_end_to_end_segment():
+    """The extra segment of `bench.py --gpus N` runs under a watchdog: when it does not come back in time (here: a wait of
+    a millisecond) rank 0 still prints the line with the resident numbers, the segment marked as timed out, exit code 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SITRK_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), SITRK_E2E_SEGMENT_TIMEOUT="0.001")
+    r = subprocess.run([sys.executable, "bench.py", "--config", "c2", "--steps", "64", "--warmup", "8", "--no-cpu-baseline"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert "timed out" in d["e2e_broadcast"]["error"] and d["value"] > 0 and d["roofline"]["launches"] >= 2
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("extra", [[], ["--e2e-full"], ["--e2e-library"], ["--e2e-library", "--e2e-full"]])
 def test_bench_end_to_end_regime_checks_against_the_oracle(extra):
     """bench.py --regime e2e (every record uploaded from pinned host memory on a copy stream, double-buffered against the
