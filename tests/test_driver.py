@@ -546,6 +546,40 @@ def test_cli_two_ranks_equals_one(tmp_path, monkeypatch, two_d_time, extra):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--rebalance", "3"], ["--full-records"]])
+def test_cli_rank_without_buoys(tmp_path, monkeypatch, extra):
+    """Three ranks, two seeds: the last rank owns no buoy from the start (and with --rebalance ranks lose and gain all
+    their buoys as the two drift) -- the empty ranges go through SeedInit, stepping, gathers and the writers, and the
+    files equal the single-rank run's."""
+    import socket
+    import torch.multiprocessing as mp
+    d1, d2 = tmp_path / "one", tmp_path / "three"
+    d1.mkdir(); d2.mkdir()
+    c = make_case(str(tmp_path), nP=2)
+    argv = ["-i", c["si3"], "-m", c["mm"], "-s", c["seed"], "-N", "TEST4", "-F"]
+    monkeypatch.chdir(d1)
+    one = drv.main(argv + ["--full-records"])
+    assert one["nP"] == 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dist_worker, args=(r, 3, port, str(d2), argv + extra, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    three = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert three["nP"] == 2 and np.array_equal(three["IDs"], one["IDs"]) and np.array_equal(three["vJIt"], one["vJIt"])
+    assert three["files"] == one["files"]
+    for f in one["files"]:
+        a = ncio.LoadNCdata(str(d1 / f), krec=-1, lmask=True)
+        b = ncio.LoadNCdata(str(d2 / f), krec=-1, lmask=True)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+
+
+@pytest.mark.gpu
 def test_sidfex_seeding_reproduces_the_reference_fixture(tmp_path, monkeypatch, golden):
     """The reference's committed seeding file tools/nc/sitrack_seeding_sidfex_19961215_00_HSS5.nc__KEEP was made by
     `generate_sidfex_seeding.py -d 1996-12-15_00:00:00 --lsidfex 1 -k 0 -S 5` (tools/cmd.sh) from tools/sidfexloc.dat.

@@ -383,6 +383,54 @@ def test_fill_values_nan_and_empty_windows():
     trk.close(); trk2.close()
 
 
+def test_empty_buoy_sets_and_empty_seed_sets():
+    """A rank of a multi-GPU run may own no buoy at all (more ranks than seeds, or every seed of its range cancelled):
+    every entry point on its path takes n = 0 -- set_buoys, step, run (fused entry), sort, count_alive, buoy_rows, fetch,
+    fetch_record, the locate functions, the projections and nemoSeed on an ice-free field."""
+    grid = syn.make_grid(48, 56, dkm=4.0, warp=0.5)
+    K = 3
+    u, v, sic = syn.make_fields(grid, K=K, seed=3, umax=0.3)
+    trk = make_tracker(grid, grid["tmask"], K)
+    for k in range(K):
+        trk.load_record(k, u[k], v[k], sic[k])
+    none2 = np.zeros((0, 2))
+    for windows in (False, True):
+        kw = dict(rec_first=np.zeros(0, np.int32), rec_last=np.zeros(0, np.int32)) if windows else {}
+        trk.ctx.set_buoys(none2, np.zeros((0, 2), dtype=np.int32), **kw)
+        trk.ctx.step(0, 0)
+        trk.ctx.run(0, 1, 5)
+        trk.ctx.sort_buoys()
+        assert trk.ctx.count_alive() == 0
+        st = trk.ctx.fetch()
+        assert st["yx"].shape == (0, 2) and st["jiT"].shape == (0, 2) and st["alive"].shape == (0,) and st["kill_rec"].shape == (0,)
+        pos, msk = trk.ctx.fetch_record(1)
+        assert pos.shape == (0, 2) and msk.shape == (0,)
+    ctx = trk.ctx
+    found, ji = ctx.find_cells(none2, np.zeros((0, 2), dtype=np.int32))
+    assert found.shape == (0,) and ji.shape == (0, 2)
+    assert ctx.cart2geo(none2).shape == (0, 2) and ctx.geo2cart(none2).shape == (0, 2)
+    # SeedInit with no seed at all, and with seeds that are all cancelled (open water everywhere)
+    latT = np.full(grid["Yf"].shape, 80.0); lonT = np.full(grid["Yf"].shape, 10.0)
+    out = sit.SeedInit(np.zeros(0, dtype=np.int64), none2, none2, latT, lonT, grid["Yf"], grid["Xf"], np.full(grid["Yf"].shape, 4.0), grid["tmask"],
+                       xIceConc=np.zeros(grid["Yf"].shape), ctx=ctx)
+    assert out[0] == 0 and out[4].shape == (0, 2) and out[5].shape == (0, 2, 4) and out[6].size == 0
+    sg = np.column_stack([np.full(7, 80.0), np.full(7, 10.0)])
+    _, yx7 = syn.make_buoys(grid, 7, seed=5, frac=0.3)
+    out = sit.SeedInit(np.arange(7), sg, yx7, latT, lonT, grid["Yf"], grid["Xf"], np.full(grid["Yf"].shape, 4.0), grid["tmask"],
+                       xIceConc=np.zeros(grid["Yf"].shape), ctx=ctx)
+    assert out[0] == 0 and out[3].size == 0 and out[6].size == 0
+    # a rank that had buoys and lost them to another rank: back to a real set afterwards
+    _, yx = syn.make_buoys(grid, 500, seed=4, frac=0.5)
+    found, ji, _ = sit.FindContainingCell(yx, syn.nearest_t_plane(grid, yx), ctx=ctx)
+    trk.set_buoys(yx[found], ji[found])
+    trk.ctx.run(0, 0, 3)
+    ref = orc.Tracker(grid, yx[found], ji[found], nthreads=4)
+    for s_ in range(3):
+        ref.step(s_, u[s_ % K].astype("f8"), v[s_ % K].astype("f8"), sic[s_ % K].astype("f8"), want_out=False)
+    st = trk.ctx.fetch()
+    assert np.array_equal(st["yx"], ref.pos) and np.array_equal(st["jiT"], ref.jiT)
+
+
 def test_everything_dies_and_stays_dead():
     grid = syn.make_grid(32, 32, dkm=4.0)
     u, v, sic = syn.make_fields(grid, K=1, umax=0.3)
