@@ -65,3 +65,44 @@ def test_full_size_properties(c3):
         ref.step(s, *f64[s % c3["K"]], want_out=False)
     assert np.array_equal(whole["yx"][sel], ref.pos)
     assert np.array_equal(whole["jiT"][sel], ref.jiT) and np.array_equal(whole["alive"][sel], ref.alive)
+
+
+@pytest.mark.parametrize("N,fused", [(9400, True), (9600, False)])
+def test_largest_meshes_at_the_32_bit_offset_limit(N, fused):
+    """Maximum sizes.  The fused kernel addresses the geometry with 32-bit byte offsets: 9400 x 9400 cells x 48 B = 4.24e9
+    is the last size class below 2^32, 9600 x 9600 (4.42e9) is beyond it and `sitrk_run` steps it record by record
+    (64-bit indexing).  Buoys sit in the LAST rows of the mesh, where the offsets are largest; both meshes are held
+    against the oracle on every buoy, through the fused entry point."""
+    K, nsteps = 2, 12
+    grid = syn.make_grid(N, N, dkm=4.0, warp=0.0)
+    u, v, sic = syn.make_fields(grid, K=K, seed=11, umax=0.6, drift=0.2)
+    sic[:, N - 200:N - 190, N - 400:N - 100] = 0.02
+    rng = np.random.default_rng(2)
+    nP = 150_000
+    j = rng.uniform(N - 330, N - 20, nP); i = rng.uniform(N - 900, N - 20, nP)     # cell indices, last rows and columns
+    yx = np.stack([np.interp(j, np.arange(N), grid["Yt"][:, 0]), np.interp(i, np.arange(N), grid["Xt"][0, :])], axis=1)
+    ji = syn.regular_host_cell(grid, yx).astype(np.int32)
+    assert (ji[:, 0].astype(np.int64) * N + ji[:, 1]).max() * 48 > (3.9e9 if fused else 2 ** 32)
+    ctx = sit.Context(0)
+    try:
+        ctx.set_grid(grid["Yf"], grid["Xf"], grid["Yu"], grid["Xu"], grid["Yv"], grid["Xv"], grid["tmask"])
+        found, ji2 = ctx.find_cells(yx, ji)
+        assert found.all() and np.array_equal(ji2, ji)
+        ctx.alloc_records(K, np.float32)
+        for k in range(K):
+            ctx.push_record(k, u[k], v[k], sic[k])
+        ctx.set_buoys(yx, ji)
+        ctx.launch_stats(reset=True)
+        for s in range(0, nsteps, K):
+            ctx.run(0, s, K)
+        st = ctx.launch_stats()
+        assert (st["fused_launches"] > 0) == fused and (st["step_launches"] == 0) == fused, st
+        out = ctx.fetch()
+    finally:
+        ctx.close()
+    ref = orc.Tracker(grid, yx, ji, nthreads=8)
+    f64 = [(u[k].astype(np.float64), v[k].astype(np.float64), sic[k].astype(np.float64)) for k in range(K)]
+    for s in range(nsteps):
+        ref.step(s, *f64[s % K], want_out=False)
+    assert np.array_equal(out["yx"], ref.pos) and np.array_equal(out["jiT"], ref.jiT) and np.array_equal(out["alive"], ref.alive)
+    assert 0 < out["alive"].sum() < nP and (out["jiT"] != ji).any()
