@@ -106,3 +106,43 @@ def test_largest_meshes_at_the_32_bit_offset_limit(N, fused):
         ref.step(s, *f64[s % K], want_out=False)
     assert np.array_equal(out["yx"], ref.pos) and np.array_equal(out["jiT"], ref.jiT) and np.array_equal(out["alive"], ref.alive)
     assert 0 < out["alive"].sum() < nP and (out["jiT"] != ji).any()
+
+
+@pytest.mark.parametrize("Nj,Ni", [(12, 65535), (32767, 12)])
+def test_longest_rows_and_columns_of_the_packed_cell(Nj, Ni):
+    """Maximum sizes, the other way: the host cell travels packed as 15 bits of jT and 16 bits of iT, so a mesh may have
+    65 535 columns or 32 767 rows.  Buoys drift along the far end of such a strip (indices next to the packing limits)
+    and off its rim; fused and record-by-record launches against the oracle."""
+    K, nsteps = 3, 24
+    grid = syn.make_grid(Nj, Ni, dkm=4.0, warp=0.0)
+    u, v, sic = syn.make_fields(grid, K=K, seed=5, umax=0.5, drift=0.3)
+    rng = np.random.default_rng(8)
+    nP = 20_000
+    if Ni > Nj:
+        j = rng.uniform(3, Nj - 4, nP); i = rng.uniform(Ni - 3000, Ni - 4, nP)
+    else:
+        j = rng.uniform(Nj - 3000, Nj - 4, nP); i = rng.uniform(3, Ni - 4, nP)
+    yx = np.stack([np.interp(j, np.arange(Nj), grid["Yt"][:, 0]), np.interp(i, np.arange(Ni), grid["Xt"][0, :])], axis=1)
+    ji = syn.regular_host_cell(grid, yx).astype(np.int32)
+    assert ji[:, 1].max() > 65000 or ji[:, 0].max() > 32500
+    f64 = [(u[k].astype(np.float64), v[k].astype(np.float64), sic[k].astype(np.float64)) for k in range(K)]
+    ref = orc.Tracker(grid, yx, ji, nthreads=8)
+    for s in range(nsteps):
+        ref.step(s, *f64[s % K], want_out=False)
+    for fuse in (32, 1):
+        ctx = sit.Context(0)
+        try:
+            ctx.set_grid(grid["Yf"], grid["Xf"], grid["Yu"], grid["Xu"], grid["Yv"], grid["Xv"], grid["tmask"])
+            ctx.alloc_records(K, np.float32)
+            for k in range(K):
+                ctx.push_record(k, u[k], v[k], sic[k])
+            ctx.set_tuning(fuse=fuse)
+            ctx.set_buoys(yx, ji)
+            ctx.set_resort(7)
+            for s in range(0, nsteps, K):
+                ctx.run(0, s, K)
+            out = ctx.fetch()
+        finally:
+            ctx.close()
+        assert np.array_equal(out["yx"], ref.pos) and np.array_equal(out["jiT"], ref.jiT) and np.array_equal(out["alive"], ref.alive)
+    assert (out["jiT"] != ji).any()
