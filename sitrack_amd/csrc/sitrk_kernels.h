@@ -492,9 +492,8 @@ struct RunArgs {
 // the two record-independent orientation terms of the velocity pick (ccw(F,V01,V11), ccw(F,U10,U11)) are
 // (re)loaded only when the buoy changes cell (3-16 % of the records); per record only the four velocity
 // candidates are loaded.  Same operations on the same operands in the same order as advance_record.
-// 91 VGPRs -> 5 waves/SIMD: the kernel is bound by fp64 issue, not by latency (-5 % vs reloading the
-// geometry every record at 8 waves/SIMD; requesting the next record's velocities one record ahead was
-// measured 7 % slower: more instructions in an issue-bound loop).
+// 78 VGPRs, no scratch -> 6 waves/SIMD (round 1: 91 VGPRs, 5 waves; requesting the next record's velocities one record
+// ahead was measured 7 % slower then: more instructions in the loop).
 // ---------------------------------------------------------------------------
 struct CellCtx {
     unsigned o1, o0;                    // byte offsets of cell (jT,iT) and of (jT-1,iT) inside a field of the record
@@ -611,8 +610,8 @@ static constexpr int kRunLdsFixed = 256 + 256 + 64;      // crossing table, its 
 #endif
 static constexpr int kRunBlock = SITRK_RUN_BLOCK;
 #ifndef SITRK_RUN_WAVES
-#define SITRK_RUN_WAVES 6               // <= 80 VGPRs (28 B of scratch): 6 waves per SIMD measured 7 % faster than 5 without spills,
-#endif                                  // 7 waves (72 VGPRs, 44 B) 25 % slower
+#define SITRK_RUN_WAVES 6               // <= 80 VGPRs (78 used, no scratch): 6 waves per SIMD measured 7 % faster than 5,
+#endif                                  // 7 waves (72 VGPRs, 19 of them spilled) 25 % slower
 template <typename FT, int UVS, bool WINDOW>
 __global__ __launch_bounds__(kRunBlock, SITRK_RUN_WAVES) void advect_run_kernel(RunArgs ra)
 {
