@@ -496,9 +496,9 @@ struct RunArgs {
 // ahead was measured 7 % slower then: more instructions in the loop).
 // ---------------------------------------------------------------------------
 struct CellCtx {
-    unsigned o1, o0;                    // byte offsets of cell (jT,iT) and of (jT-1,iT) inside a field of the record
-                                        // (32 bits: sitrk_set_grid keeps Nj*Ni*8 below 2^32) -> a record's velocities are
-                                        // loaded as (scalar record pointer + this offset), no address arithmetic per record
+    unsigned o1;                        // byte offset of cell (jT,iT) inside a field of the record (32 bits: sitrk_set_grid keeps
+                                        // Nj*Ni*8 below 2^32) -> a record's velocities are loaded as (scalar record pointer + this
+                                        // offset [- one row for v[jT-1,iT]]), next to no address arithmetic per record
     pt F11, U11, V11, F10, U10, F01, V01, F00;
     unsigned ori;                       // the cell's orientation byte as loaded: bit 0 = ccw(F11,V01,V11), bit 1 = ccw(F11,U10,U11);
                                         // unpacked where it is used, one record later, not behind its own load in the crossing path
@@ -509,7 +509,7 @@ template <unsigned ES>
 __device__ __forceinline__ void load_ctx(const StepArgs &a, const char *__restrict__ gb, unsigned kcell, CellCtx &x)
 {
     const unsigned Ni = (unsigned)a.Ni;
-    x.o1 = kcell * ES; x.o0 = (kcell - Ni) * ES;
+    x.o1 = kcell * ES;
     const unsigned k48 = kcell * (unsigned)sizeof(CellGeo), k48b = k48 - Ni * (unsigned)sizeof(CellGeo);
     x.F11 = geo_pt(gb, k48, 0); x.U11 = geo_pt(gb, k48, 16); x.V11 = geo_pt(gb, k48, 32);
     x.F10 = geo_pt(gb, k48, -48); x.U10 = geo_pt(gb, k48, -32);
@@ -563,7 +563,7 @@ __device__ __forceinline__ void load_ctx_lds(const StepArgs &a, const Patch &pa,
                                              unsigned kcell, unsigned lo, CellCtx &x)
 {
     const unsigned Ni = (unsigned)a.Ni;
-    x.o1 = kcell * ES; x.o0 = (kcell - Ni) * ES;
+    x.o1 = kcell * ES;
     const unsigned k48 = kcell * (unsigned)sizeof(CellGeo), k48b = k48 - Ni * (unsigned)sizeof(CellGeo);
     x.U11 = geo_pt(gb, k48, 16); x.V11 = geo_pt(gb, k48, 32); x.U10 = geo_pt(gb, k48, -32); x.V01 = geo_pt(gb, k48b, 32);
     x.ori = (unsigned)(uint8_t)a.orient[kcell];
@@ -610,10 +610,13 @@ static constexpr int kRunLdsFixed = 256 + 256 + 64;      // crossing table, its 
 #endif
 static constexpr int kRunBlock = SITRK_RUN_BLOCK;
 #ifndef SITRK_RUN_WAVES
-#define SITRK_RUN_WAVES 6               // <= 80 VGPRs (78 used, no scratch): 6 waves per SIMD measured 7 % faster than 5,
-#endif                                  // 7 waves (72 VGPRs, 19 of them spilled) 25 % slower
+#define SITRK_RUN_WAVES 7               // 72 VGPRs, no scratch (the cell is stored behind a lane flag, crel and the row-below offset are
+#endif                                  // derived where they are used): +2.6 % over 6 waves; 8 waves (64 VGPRs) spill 32 registers
+#ifndef SITRK_RUN_WAVES_WINDOW
+#define SITRK_RUN_WAVES_WINDOW 6        // the form with per-buoy record windows carries two more registers: 9 spilled at 7 waves
+#endif
 template <typename FT, int UVS, bool WINDOW>
-__global__ __launch_bounds__(kRunBlock, SITRK_RUN_WAVES) void advect_run_kernel(RunArgs ra)
+__global__ __launch_bounds__(kRunBlock, WINDOW ? SITRK_RUN_WAVES_WINDOW : SITRK_RUN_WAVES) void advect_run_kernel(RunArgs ra)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *s_tab = (int *)smem;                            // CrossTab, 64 ints
@@ -680,11 +683,11 @@ __global__ __launch_bounds__(kRunBlock, SITRK_RUN_WAVES) void advect_run_kernel(
     int first = 0, last = 0x7fffffff;
     if (WINDOW) { first = a.first[p]; last = a.last[p]; }
     pt P = nt ? load_pt_nt(&a.pos[p]) : a.pos[p];
-    const int32_t c0 = c;
-    bool moved = false;
+    bool moved = false, recelled = false;               // (lane flags: the cell is stored only if it changed)
     CellCtx x;
     // position of the host cell inside the patch, packed like the cell itself (jr << 16 | ir), and the LDS offset of its record
-    int crel = c - ((pa.R0 << 16) | pa.C0);
+    const int porg = (pa.R0 << 16) | pa.C0;
+    int crel = c - porg;
     const unsigned geo_la = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)s_geo - (unsigned)kLdsBias;
     unsigned lo = geo_la + patch_off(pa, crel >> 16, crel & 0xffff);
     bool inl = patch_covers(pa, crel >> 16, crel & 0xffff);
@@ -710,7 +713,7 @@ __global__ __launch_bounds__(kRunBlock, SITRK_RUN_WAVES) void advect_run_kernel(
         }
         // the four velocity candidates u[jT,iT-1], u[jT,iT], v[jT-1,iT], v[jT,iT]
         FT fu0 = *(const FT *)(ub + x.o1 - sizeof(FT)), fu1 = *(const FT *)(ub + x.o1);
-        FT fv0 = *(const FT *)(vb + x.o0), fv1 = *(const FT *)(vb + x.o1);
+        FT fv0 = *(const FT *)(vb + (x.o1 - (unsigned)a.Ni * (unsigned)sizeof(FT))), fv1 = *(const FT *)(vb + x.o1);
         // ... and the Survive byte of the cell's 8 neighbours for this record (used only if the buoy leaves the cell)
         unsigned k9 = *(const uint8_t *)(kb + (x.o1 >> (sizeof(FT) == 4 ? 2 : 3)));
         double zU, zV;
@@ -758,7 +761,8 @@ __global__ __launch_bounds__(kRunBlock, SITRK_RUN_WAVES) void advect_run_kernel(
                 resolve_crossing_tab(P, Pn, x.F00, x.F01, x.F11, x.F10, kcell * (unsigned)sizeof(CellGeo), k9, gb, s_tab, dcell, dk, killed);
             }
             c += dcell;
-            crel += dcell;
+            recelled = true;
+            const int crel = c - porg;                  // (derived, not carried from record to record; c is a live cell here)
             // (a killed buoy's destination is inside the mesh too: its context is loaded unconditionally, which keeps the
             // loads out of the shadow of the Survive test)
             if (inl) {
@@ -788,7 +792,7 @@ __global__ __launch_bounds__(kRunBlock, SITRK_RUN_WAVES) void advect_run_kernel(
         if (nt) store_pt_nt(&a.pos[pe], P);
         else a.pos[pe] = P;
     }
-    if (c != c0) a.cell[pe] = c;
+    if (recelled) a.cell[pe] = c;
 }
 
 #ifdef SITRK_DIAG
