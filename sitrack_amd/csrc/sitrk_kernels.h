@@ -492,8 +492,8 @@ struct RunArgs {
 // the two record-independent orientation terms of the velocity pick (ccw(F,V01,V11), ccw(F,U10,U11)) are
 // (re)loaded only when the buoy changes cell (3-16 % of the records); per record only the four velocity
 // candidates are loaded.  Same operations on the same operands in the same order as advance_record.
-// 78 VGPRs, no scratch -> 6 waves/SIMD (round 1: 91 VGPRs, 5 waves; requesting the next record's velocities one record
-// ahead was measured 7 % slower then: more instructions in the loop).
+// 72 VGPRs, no scratch -> 7 waves/SIMD (78 -> 6 with per-buoy record windows; round 1: 91 VGPRs, 5 waves; requesting the
+// next record's velocities one record ahead was measured 7 % slower then: more instructions in the loop).
 // ---------------------------------------------------------------------------
 struct CellCtx {
     unsigned o1;                        // byte offset of cell (jT,iT) inside a field of the record (32 bits: sitrk_set_grid keeps
@@ -613,7 +613,8 @@ static constexpr int kRunBlock = SITRK_RUN_BLOCK;
 #define SITRK_RUN_WAVES 7               // 72 VGPRs, no scratch (the cell is stored behind a lane flag, crel and the row-below offset are
 #endif                                  // derived where they are used): +2.6 % over 6 waves; 8 waves (64 VGPRs) spill 32 registers
 #ifndef SITRK_RUN_WAVES_WINDOW
-#define SITRK_RUN_WAVES_WINDOW 6        // the form with per-buoy record windows carries two more registers: 9 spilled at 7 waves
+#define SITRK_RUN_WAVES_WINDOW 6        // the form with per-buoy record windows carries two more registers: 9 spilled at 7 waves (13-25
+                                        // with the window packed into one register, as a single test, or as a predicate on the body)
 #endif
 template <typename FT, int UVS, bool WINDOW>
 __global__ __launch_bounds__(kRunBlock, WINDOW ? SITRK_RUN_WAVES_WINDOW : SITRK_RUN_WAVES) void advect_run_kernel(RunArgs ra)
