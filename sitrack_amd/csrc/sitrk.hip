@@ -587,6 +587,12 @@ SITRK_API int sitrk_set_buoys(sitrk_t *h, int64_t nP, const double *yx, const in
         rim = rim || j < 2 || i < 2;
     }
     h->rim_buoys = rim;
+    h->win_first_max = INT32_MIN; h->win_last_min = INT32_MAX;
+    if (h->windowed)
+        for (int64_t p = 0; p < nP; p++) {
+            h->win_first_max = std::max(h->win_first_max, rec_first[p]);
+            h->win_last_min = std::min(h->win_last_min, rec_last[p]);
+        }
     for (int b = 0; b < 2; b++) {
         HIPCHK(dev_alloc(&h->st[b].pos, (size_t)nP));
         HIPCHK(dev_alloc(&h->st[b].cell, (size_t)nP));
@@ -687,18 +693,25 @@ SITRK_API int sitrk_sort_buoys(sitrk_t *h)
     return SITRK_OK;
 }
 
+// records [jrec0, jrec0 + n) need the per-buoy window test unless they lie inside every buoy's window
+static inline bool window_test_needed(const sitrk_ctx *h, int jrec0, int n)
+{
+    return h->windowed && !(jrec0 >= h->win_first_max && (int64_t)jrec0 + n - 1 <= h->win_last_min);
+}
+
 template <typename FT, int BLOCK>
 static void launch_step_b(sitrk_ctx *h, const StepArgs &a)
 {
+    const bool windowed = window_test_needed(h, a.jrec, 1);
     dim3 grid(nblocks(a.nP, BLOCK)), block(BLOCK);
     if (h->uv_strategy == 1) {
-        if (h->windowed) hipLaunchKernelGGL((advect_step_kernel<FT, 1, true, BLOCK>), grid, block, 0, h->stream, a);
+        if (windowed) hipLaunchKernelGGL((advect_step_kernel<FT, 1, true, BLOCK>), grid, block, 0, h->stream, a);
         else hipLaunchKernelGGL((advect_step_kernel<FT, 1, false, BLOCK>), grid, block, 0, h->stream, a);
     } else if (h->uv_strategy == 2) {
-        if (h->windowed) hipLaunchKernelGGL((advect_step_kernel<FT, 2, true, BLOCK>), grid, block, 0, h->stream, a);
+        if (windowed) hipLaunchKernelGGL((advect_step_kernel<FT, 2, true, BLOCK>), grid, block, 0, h->stream, a);
         else hipLaunchKernelGGL((advect_step_kernel<FT, 2, false, BLOCK>), grid, block, 0, h->stream, a);
     } else {
-        if (h->windowed) hipLaunchKernelGGL((advect_step_kernel<FT, 0, true, BLOCK>), grid, block, 0, h->stream, a);
+        if (windowed) hipLaunchKernelGGL((advect_step_kernel<FT, 0, true, BLOCK>), grid, block, 0, h->stream, a);
         else hipLaunchKernelGGL((advect_step_kernel<FT, 0, false, BLOCK>), grid, block, 0, h->stream, a);
     }
 }
@@ -768,16 +781,17 @@ static void launch_run(sitrk_ctx *h, const RunArgs &ra)
     dim3 grid(nblocks(ra.s.nP, kRunBlock)), block(kRunBlock);
     // dynamic LDS: tables + the patch's F-points
     const size_t lds = kRunLdsFixed + (size_t)ra.patch_cells * sizeof(pt);
+    const bool windowed = window_test_needed(h, ra.s.jrec, ra.nrec);
 #define SITRK_LAUNCH_RUN(KERNEL)                                                                          \
     do {                                                                                                  \
         if (h->uv_strategy == 1) {                                                                        \
-            if (h->windowed) hipLaunchKernelGGL((KERNEL<FT, 1, true>), grid, block, lds, h->stream, ra);  \
+            if (windowed) hipLaunchKernelGGL((KERNEL<FT, 1, true>), grid, block, lds, h->stream, ra);     \
             else hipLaunchKernelGGL((KERNEL<FT, 1, false>), grid, block, lds, h->stream, ra);             \
         } else if (h->uv_strategy == 2) {                                                                 \
-            if (h->windowed) hipLaunchKernelGGL((KERNEL<FT, 2, true>), grid, block, lds, h->stream, ra);  \
+            if (windowed) hipLaunchKernelGGL((KERNEL<FT, 2, true>), grid, block, lds, h->stream, ra);     \
             else hipLaunchKernelGGL((KERNEL<FT, 2, false>), grid, block, lds, h->stream, ra);             \
         } else {                                                                                          \
-            if (h->windowed) hipLaunchKernelGGL((KERNEL<FT, 0, true>), grid, block, lds, h->stream, ra);  \
+            if (windowed) hipLaunchKernelGGL((KERNEL<FT, 0, true>), grid, block, lds, h->stream, ra);     \
             else hipLaunchKernelGGL((KERNEL<FT, 0, false>), grid, block, lds, h->stream, ra);             \
         }                                                                                                 \
     } while (0)

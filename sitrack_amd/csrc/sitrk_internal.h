@@ -93,6 +93,8 @@ struct sitrk_ctx {
     // buoys
     int64_t nP = 0;
     bool windowed = false;
+    int32_t win_first_max = 0, win_last_min = 0;   // over all buoys: a launch whose records lie in [first_max, last_min] steps
+                                                   // every live buoy at every record -> the form without the window test
     bool rim_buoys = false;             // some buoy was set in a cell with jT < 2 or iT < 2 (numpy negative-index wrap possible)
     sitrk::BuoyState st[2];             // double buffer for the sort
     int cur = 0;
