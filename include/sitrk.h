@@ -89,10 +89,12 @@ int sitrk_set_params(sitrk_t *h, double rdt, int uv_strategy, double rmin_conc);
  * the once-per-step position/cell streams; "sort_tile" (tile_j*256 + tile_i, 0 = row-major):
  * order of the cell sort, tile-major tiles of tile_j x tile_i cells; "locate_bruteforce" (0/1):
  * SeedInit scans the whole grid per seed like the reference instead of the bounding-sphere search;
- * "patch_kb" (0..63, default 40) / "patch_margin": LDS bytes per workgroup that the fused kernel may fill with the geometry of
- * the cells around its buoys (0 = none: every geometry read goes to global memory), and the widest margin of cells it takes;
- * "step_block" (256/512/1024): workgroup size of the one-record kernel; "fuse" (1..32): consecutive resident records advanced per launch by sitrk_run (loop interchange: the
- * buoys are independent, each lane keeps its buoy in registers across the records). */
+ * "patch_kb" (0..63, default 16) / "patch_margin" (0..64, default 8): KB of LDS per workgroup that the fused kernel may fill with
+ * the F-points of the cells around its buoys (0 = none: every geometry read goes to global memory), and the widest margin of
+ * cells it takes around their bounding box; "xcd_group" (0..4096, default 16): runs of that many consecutive workgroups of the
+ * fused kernel share an XCD (its L2); "step_block" (256/512/1024): workgroup size of the one-record kernel; "fuse" (1..32):
+ * consecutive resident records advanced per launch by sitrk_run (loop interchange: the buoys are independent, each lane keeps
+ * its buoy in registers across the records). */
 int sitrk_set_tuning(sitrk_t *h, const char *knob, int value);
 
 /* ---- model records (u_ice, v_ice, siconc) -------------------------------
@@ -165,7 +167,9 @@ int sitrk_set_resort(sitrk_t *h, int resort_every);
  * model record `jrec`.  Asynchronous. */
 int sitrk_step(sitrk_t *h, int slot, int jrec);
 
-/* nsteps records jrec0, jrec0+1, ... using slots (slot0 + k) % nslots */
+/* nsteps records jrec0, jrec0+1, ... using slots (slot0 + k) % nslots; consecutive resident records go into one launch
+ * (knob "fuse"; never across a re-sort or the slot ring).  Buoy sets with per-buoy record windows run the kernel form
+ * without the window test for every launch whose records lie inside all windows. */
 int sitrk_run(sitrk_t *h, int slot0, int jrec0, int nsteps);
 /* What sitrk_run / sitrk_step really launched since the last reset: fused launches of advect_run_kernel, the records
  * they advanced in total (a launch is cut short at a re-sort and at the end of a run), and one-record launches of
