@@ -456,35 +456,54 @@ class NC4Writer:
     def _write_chunks_parallel(self, d, a, chunk, level, fill):
         """Shuffle + deflate of every (1 x C) chunk on a thread pool (zlib releases the GIL), raw chunks handed to
         H5Dwrite_chunk: the file is what H5Dwrite's filter pipeline would have produced, in a fraction of the time --
-        libhdf5 deflates one chunk after the other on the calling thread, 45 s for the 10^7-buoy files at level 9."""
+        libhdf5 deflates one chunk after the other on the calling thread, 45 s for the 10^7-buoy files at level 9.
+        The chunks of ALL variables share one pool and are only queued here (a variable has 2 x 10 chunks at 10^7 buoys:
+        on 16 threads its second round would keep 4 of them busy); close() -- or flush() -- hands them to the library."""
         import zlib
         from concurrent.futures import ThreadPoolExecutor
         nrec, n = a.shape
         cw = chunk[1]
         isz = a.dtype.itemsize
-        jobs = [(r, c0) for r in range(nrec) for c0 in range(0, n, cw)]
 
-        def pack(job):
-            r, c0 = job
+        def pack(r, c0):
             seg = a[r, c0:c0 + cw]
             if seg.shape[0] < cw:                                  # an edge chunk is stored whole
                 pad = np.full(cw, 0 if fill is None else fill, dtype=a.dtype)
                 pad[:seg.shape[0]] = seg
                 seg = pad
             shuffled = np.ascontiguousarray(seg.view(np.uint8).reshape(cw, isz).T)      # the SHUFFLE filter: byte planes
-            return job, zlib.compress(shuffled.tobytes(), level)
-        nthreads = min(16, os.cpu_count() or 1, len(jobs))
-        with ThreadPoolExecutor(nthreads) as ex:
-            for (r, c0), blob in ex.map(pack, jobs):
+            return zlib.compress(shuffled.tobytes(), level)
+        if getattr(self, "_pool", None) is None:
+            self._pool = ThreadPoolExecutor(min(16, os.cpu_count() or 1))
+            self._pending = []
+        for r in range(nrec):
+            for c0 in range(0, n, cw):
+                self._pending.append((d, r, c0, self._pool.submit(pack, r, c0)))
+
+    def flush(self):
+        """hand the queued chunks to libhdf5 (in the order they were queued; the calls themselves are serial)"""
+        pending, self._pending = getattr(self, "_pending", []), []
+        try:
+            for d, r, c0, fut in pending:
+                blob = fut.result()
                 off = (hsize_t * 2)(r, c0)
                 if self.L.H5Dwrite_chunk(d, 0, 0, off, len(blob), blob) < 0:
                     raise OSError("H5Dwrite_chunk failed at (%d,%d)" % (r, c0))
+        finally:
+            for _, _, _, fut in pending:
+                fut.cancel()
 
     def close(self):
         """Turn the coordinate variables into dimension scales, attach every variable to its scales, close."""
         if self.fid < 0:
             return
         L, H = self.L, self.H
+        try:
+            self.flush()
+        finally:
+            if getattr(self, "_pool", None) is not None:
+                self._pool.shutdown(wait=True)
+                self._pool = None
         for dname, (size, unl, dimid) in self.dims.items():
             if dname not in self.vars:
                 raise ValueError("dimension %s needs its coordinate variable" % dname)
