@@ -44,6 +44,107 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 
 VALU_PEAK_GINST = 1024 * 2.4 / 4.0   # 256 CUs x 4 SIMDs, 2.4 GHz max clock, one wave64 VALU instruction per 4 cycles per SIMD
                                      # (the rate SQ_ACTIVE_INST_VALU counts in; MI355X_MICROARCH.md, cycle constants) = 614.4 G/s
 
+# ---- one line, whatever happens (N > 1) --------------------------------------------------------------------------
+# A multi-rank run must never leave the driver guessing: the JSON line is printed exactly once, and any failure of the
+# exchange path (a collective that raises, one that never completes, a rank that dies and has the launcher terminate the
+# others) prints it with "degraded": "<reason>" and "value": null, and the process exits NON-ZERO.  Nothing is retried
+# in-process and nothing is re-exec'ed.
+import threading
+
+_STATE = {"base": {}, "phase": "start", "t_phase": time.time(), "printed": False, "rank": 0, "multi": False}
+_EMIT_LOCK = threading.Lock()
+
+EXIT_E2E_FAILED = 3        # the resident numbers are in the line; the end-to-end broadcast segment failed or hung
+EXIT_DEGRADED = 4          # the record broadcast (or another collective `value` depends on) failed: value is null
+EXIT_EXCEPTION = 5         # any other exception on a multi-rank run
+EXIT_NO_PROGRESS = 6       # watchdog: a phase did not end (a collective that never completes)
+EXIT_TERMINATED = 7        # the launcher terminated this rank (another rank failed)
+
+
+def _phase(name):
+    _STATE["phase"] = name
+    _STATE["t_phase"] = time.time()
+
+
+def _emit(line):
+    """print the JSON line once, whoever gets here first (main flow, watchdog thread or signal watcher)"""
+    with _EMIT_LOCK:
+        if _STATE["printed"]:
+            return False
+        _STATE["printed"] = True
+        sys.stdout.write(json.dumps(line) + "\n")
+        sys.stdout.flush()
+        return True
+
+
+def _degraded_exit(reason, code):
+    """rank 0: the line with value null and the reason; every rank: leave with a non-zero code, at once, without touching
+    a communicator that may be stuck (no orderly teardown is possible then)"""
+    try:
+        if _STATE["rank"] == 0:
+            line = dict(_STATE["base"])
+            line.update({"value": None, "degraded": reason, "phase": _STATE["phase"]})
+            _emit(line)
+        sys.stderr.write("bench.py rank %d: %s (phase %s) -> exit %d\n" % (_STATE["rank"], reason, _STATE["phase"], code))
+        sys.stderr.flush()
+    finally:
+        os._exit(code)
+
+
+def _start_guards():
+    """multi-rank runs only.  (1) a watcher on a signal wake-up pipe: SIGTERM from the launcher reaches it even while the
+    main thread sits inside a collective (Python-level handlers only run between bytecodes of the main thread);
+    (2) a no-progress watchdog, longer than the process group's own timeout so that torch's error surfaces first."""
+    import signal
+    rfd, wfd = os.pipe()
+    os.set_blocking(wfd, False)
+    signal.set_wakeup_fd(wfd, warn_on_full_buffer=False)
+    signal.signal(signal.SIGTERM, lambda *_: None)        # installs the C-level handler that writes to the pipe
+
+    def _sig_watch():
+        while True:
+            b = os.read(rfd, 1)
+            if b and b[0] == signal.SIGTERM:
+                _degraded_exit("terminated by the launcher (SIGTERM): another rank failed or the job was cancelled", EXIT_TERMINATED)
+
+    def _watchdog():
+        limit = float(os.environ.get("SITRK_BENCH_PHASE_TIMEOUT", "420"))
+        while True:
+            time.sleep(min(5.0, limit / 4))
+            if _STATE["phase"] == "done":
+                return
+            if time.time() - _STATE["t_phase"] > limit:
+                _degraded_exit("no progress for %.0f s (a collective that never completes?)" % limit, EXIT_NO_PROGRESS)
+
+    threading.Thread(target=_sig_watch, daemon=True).start()
+    threading.Thread(target=_watchdog, daemon=True).start()
+
+
+def _device_identity(torch, dev):
+    """what tells two GPUs apart: index, name, UUID (or PCI address) -- gathered from every rank into the line"""
+    out = {"device": int(dev)}
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        out["name"] = pr.name
+        u = getattr(pr, "uuid", None)
+        out["uuid"] = str(u) if u is not None else None
+        for k in ("pci_bus_id", "pci_device_id", "pci_domain_id"):
+            if hasattr(pr, k):
+                out[k] = int(getattr(pr, k))
+    except Exception as e:                                          # noqa: BLE001
+        out["error"] = repr(e)
+    return out
+
+
+def _slot_checksum(torch, sd, ctx, slot):
+    """exact checksum of a resident slab as it sits in HBM: sum of its 32-bit words as int64 (then the mask is re-derived,
+    because handing out the slot's pointer marks it as rewritten)"""
+    t = sd.slot_tensor(ctx, slot)
+    c = int(t.view(torch.int32).to(torch.int64).sum().item())
+    ctx.commit_record(slot)
+    return c
+
+
 CONFIGS = {
     # name: (Nj, Ni, buoys per GPU, label)
     "c3": (4096, 4096, 10_000_000, "C3: synthetic 4096x4096 C-grid, 1e7 buoys/GPU, fp32 records"),
@@ -127,6 +228,8 @@ def cpu_baseline_check(ctx, grid, u, v, sic, yx, ji, nsteps, uv_strategy, nS=200
     f64 = [(u[k].astype(np.float64), v[k].astype(np.float64), sic[k].astype(np.float64)) for k in range(K)]
     for s in range(nsteps):
         ref.step(s, *f64[s % K], want_out=False)
+        if s % 200 == 199:
+            _phase("oracle check")                      # (keeps the no-progress watchdog of multi-rank runs quiet)
         if s % 2000 == 1999:
             print("check: oracle at step %d / %d" % (s + 1, nsteps), file=sys.stderr, flush=True)
     st = ctx.fetch()
@@ -263,7 +366,14 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+    _STATE["rank"] = rank
+    _STATE["base"] = {"metric": "particle-steps/s", "value": None, "unit": "particle-steps/s", "n_gpus": world, "steps": a.steps,
+                      "warmup": a.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+                      "data": "synthetic"}
     if world > 1 or force:
+        _STATE["multi"] = True
+        _start_guards()
+        _phase("init_process_group")
         import torch.distributed as dist
         torch.cuda.set_device(dev)
         import datetime
@@ -275,6 +385,19 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     red_dev = "cuda" if backend == "nccl" else "cpu"        # where the small reduction tensors live
+
+    # who takes part: every rank's (rank, local rank, device index, device UUID, host, pid), gathered through the process
+    # group itself -- the line proves that N ranks on N different devices exchanged data, or says which did not
+    rccl = None
+    if dist is not None:
+        _phase("gather identities")
+        import socket
+        me = dict(_device_identity(torch, dev), rank=rank, local_rank=local_rank, host=socket.gethostname(), pid=os.getpid())
+        ids = [None] * dist.get_world_size()
+        dist.all_gather_object(ids, me)
+        uu = [(d.get("host"), d.get("uuid") or d.get("pci_bus_id") or d.get("device")) for d in ids]
+        rccl = {"backend": "rccl (torch.distributed nccl)" if backend == "nccl" else backend, "world": dist.get_world_size(),
+                "ranks": ids, "distinct_devices": len(set(uu))}
 
     if a.config == "auto":
         a.config = "c3" if world == 1 else "c4"
@@ -309,9 +432,14 @@ def main():
         u, v, sic = syn.make_fields(grid, K=K, seed=2024, umax=0.3, drift=0.05)
         slabs_host = [sd.pack_slab(u[k], v[k], sic[k], np.float32) for k in range(K)]
     records_via = "host upload" if dist is None else ("RCCL broadcast from rank 0" if backend == "nccl" else backend + " broadcast from rank 0")
+    _STATE["base"]["config"] = {"workload": label, "grid": [Nj, Ni], "buoys_per_gpu": nP, "buoys_total": nP * world, "regime": a.regime,
+                                "partition": "buoy-range x%d" % world, "records_via": records_via}
     if a.regime == "resident":
+        _phase("record broadcast")
         try:
             for k in range(K):
+                if dist is not None and os.environ.get("SITRK_BENCH_FAIL_BCAST") == str(rank) and k == K // 2:
+                    raise RuntimeError("injected failure of the record broadcast (SITRK_BENCH_FAIL_BCAST)")     # tests only
                 if dist is not None and backend == "nccl":
                     sd.broadcast_record(ctx, k, slabs_host[k] if rank == 0 else None, src=0)
                 elif world > 1:
@@ -319,16 +447,34 @@ def main():
                     ctx.push_record(k, *sd.split_slab(slab, Nj, Ni))
                 else:
                     ctx.push_record(k, u[k], v[k], sic[k])
-        except Exception as e:                          # noqa: BLE001 -- keep the scaling run alive: the records are deterministic
-            if dist is None or force:
+        except Exception as e:                          # noqa: BLE001
+            if dist is None:
                 raise
-            print("rank %d: record broadcast failed (%r); generating the records locally" % (rank, e), file=sys.stderr)
-            records_via = "generated on every rank (broadcast failed: %s)" % type(e).__name__
-            if u is None:
-                u, v, sic = syn.make_fields(grid, K=K, seed=2024, umax=0.3, drift=0.05)
-            for k in range(K):
-                ctx.push_record(k, u[k], v[k], sic[k])
+            # The exchange is what a multi-rank run is there to show: no local regeneration behind the driver's back.
+            # Rank 0 prints the line with value null and the reason; every rank that got here leaves non-zero (the
+            # launcher then terminates the others, whose SIGTERM watcher does the same).
+            import traceback
+            traceback.print_exc()
+            _degraded_exit("record broadcast failed on rank %d: %r" % (rank, e), EXIT_DEGRADED)
+        if dist is not None:
+            # proof that every rank holds rank 0's bytes: exact checksums of the resident slabs, as they sit in HBM on each
+            # rank, gathered and compared with rank 0's (and, on rank 0, with the host arrays they were generated as)
+            _phase("slab checksums")
+            ctx.sync(); torch.cuda.synchronize()
+            probe = sorted({0, K // 2, K - 1})
+            mine = torch.tensor([_slot_checksum(torch, sd, ctx, k) for k in probe], dtype=torch.int64, device=red_dev)
+            allc = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+            dist.all_gather(allc, mine)
+            allc = [[int(x) for x in t.cpu()] for t in allc]
+            rccl["slab_checksum_slots"] = probe
+            rccl["slab_checksums"] = allc
+            rccl["slab_checksum_ok"] = all(c == allc[0] for c in allc)
+            if rank == 0:
+                host = [int(slabs_host[k].view(np.int32).astype(np.int64).sum()) for k in probe]
+                rccl["slab_checksum_matches_source"] = host == allc[0]
+            ctx.sync(); torch.cuda.synchronize()
 
+    _phase("set_buoys")
     ctx.set_buoys(yx, ji, sort=not a.no_sort)
     resort = a.resort if a.resort >= 0 else 512        # measured over 6000 steps: 512 > 256 > 128 > never
     ctx.set_resort(0 if a.no_sort else resort)
@@ -347,6 +493,7 @@ def main():
 
         def timed_run(s0, nsteps, nfuse):
             """nsteps records from step s0 at `nfuse` records per launch: (wall s, HIP-event ms, what was really launched)"""
+            _phase("timed stepping, %d records per launch" % nfuse)
             ctx.set_tuning(fuse=nfuse)
             barrier()
             ctx.launch_stats(reset=True)
@@ -472,7 +619,14 @@ def main():
         dt = time.perf_counter() - t0
         ctx.set_stream(None)
         e2e_bytes_per_step = band["bytes"] / float(a.warmup + a.steps)
+    value_per_rank = None
     if dist is not None:                                 # the slowest rank sets every reported time
+        _phase("reductions")
+        mine = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+        each = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(each, mine)
+        per = [float(nP) * a.steps / float(x[0]) for x in each]          # every rank's own particle-steps/s over the timed region
+        value_per_rank = {"min": min(per), "max": max(per), "all": per}
         extra = [per_record[0], per_record[1]] if per_record is not None else [0.0, 0.0]
         t = torch.tensor([dt, ev_ms] + extra + [eight or 0.0], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -482,6 +636,7 @@ def main():
         if eight is not None:
             eight = float(t[4])
 
+    _phase("count alive")
     nalive = ctx.count_alive()
     if dist is not None:
         t = torch.tensor([nalive], dtype=torch.int64, device=red_dev)
@@ -507,28 +662,32 @@ def main():
         except Exception:                                          # noqa: BLE001
             return None
 
+    copy_GBps = measured_copy_GBps() if (rank == 0 and per_record is not None) else None
+
     e2e_bcast = None
     e2e_hung = False
     if dist is not None and a.regime == "resident" and backend == "nccl" and not a.no_e2e_broadcast:
         # Everything `value` needs is measured and reduced by now.  The extra segment runs under a watchdog: if a collective
         # in it never completes on some rank, every rank gives up after the same wait, rank 0 still prints the line (with
         # the segment marked as timed out) and the processes leave without touching the stuck communicator.
-        import threading
         box = {}
 
         def _segment():
             torch.cuda.set_device(dev)
             box["out"] = e2e_broadcast_segment(ctx, dist, torch, sd, rank, world, slabs_host, K, a.warmup + a.steps * 3, Nj, Ni)
 
+        _phase("e2e broadcast segment")
         th = threading.Thread(target=_segment, daemon=True)
         th.start()
         th.join(timeout=float(os.environ.get("SITRK_E2E_SEGMENT_TIMEOUT", "150")))
         if th.is_alive():
             e2e_hung = True
-            e2e_bcast = {"error": "timed out (a collective of the segment did not complete); the resident numbers above are unaffected"}
+            e2e_bcast = {"error": "timed out (a collective of the segment did not complete); the resident numbers were measured and "
+                                  "reduced before the segment started; exit code %d" % EXIT_E2E_FAILED}
         else:
             e2e_bcast = box.get("out", {"error": "segment thread ended without a result"})
 
+    _phase("line")
     if rank == 0:
         total = float(nP) * world * a.steps
         step_s = (ev_ms / 1e3) / a.steps                     # avg time per record, HIP events, library stream
@@ -615,7 +774,7 @@ def main():
             line["per_record_launch"] = {
                 "value": total / dt1, "ms_per_step": 1e3 * dt1 / a.steps, "kernel": "advect_step_kernel",
                 "launches": st1["step_launches"], "roofline": roofline_step(ev1 / max(st1["step_launches"], 1))}
-            cp = measured_copy_GBps()
+            cp = copy_GBps
             if cp:
                 rr = line["per_record_launch"]["roofline"]
                 rr["device_copy_GBps_measured"] = cp                 # the practical ceiling next to the 8 TB/s spec
@@ -623,20 +782,42 @@ def main():
         if eight is not None:
             line["eight_records_per_launch"] = {"value": total / eight, "ms_per_step": 1e3 * eight / a.steps,
                                                 "note": "same kernel, 8 records per launch (SURVEY 8d keeps K = 8 records resident)"}
+        if rccl is not None:
+            rccl["value_per_rank"] = value_per_rank
+            line["rccl"] = rccl
         if e2e_bcast is not None:
             line["e2e_broadcast"] = e2e_bcast
-        if world == 1 and a.regime == "resident" and a.config == "c3" and a.buoys == 0 and not a.no_c2:
+        # (nothing below touches the GPU when the segment's thread is stuck inside a collective)
+        if world == 1 and not e2e_hung and a.regime == "resident" and a.config == "c3" and a.buoys == 0 and not a.no_c2:
             line["c2"] = c2_subrun(sit, syn, dev, a)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(grid, u, v, sic, yx, ji, a.cpu_seconds, a.uv_strategy)
-        print(json.dumps(line), flush=True)
+        if rccl is not None and rccl.get("slab_checksum_ok") is False:
+            line["degraded"] = "the resident slabs differ between ranks (slab_checksums)"
+        _emit(line)
+    e2e_failed = e2e_bcast is not None and "error" in e2e_bcast
     if e2e_hung:
-        sys.stderr.flush()
-        os._exit(0)                                     # a thread is stuck inside a collective: no orderly teardown possible
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(EXIT_E2E_FAILED)                       # a thread is stuck inside a collective: no orderly teardown possible
+    _phase("teardown")
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+    _phase("done")
+    if e2e_failed:
+        sys.exit(EXIT_E2E_FAILED)                       # a collective of the segment raised: the line says so, the code too
+    if rccl is not None and rccl.get("slab_checksum_ok") is False:
+        sys.exit(EXIT_DEGRADED)
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:                          # noqa: BLE001
+        if not _STATE["multi"]:
+            raise
+        import traceback
+        traceback.print_exc()
+        _degraded_exit("exception on rank %d: %r" % (_STATE["rank"], e), EXIT_EXCEPTION)

@@ -111,9 +111,13 @@ int   sitrk_push_record(sitrk_t *h, int slot, const void *u, const void *v, cons
  * sitrk_stage_acquire hands out the next staging buffer as three arrays of nrows x Ni elements of the records' dtype
  * (blocks until the upload that last used the buffer has drained); the caller fills them and sitrk_stage_submit queues
  * them as rows [j0, j0 + nrows) of `slot` exactly like sitrk_push_record_rows (whole record: nrows = Nj, j0 = 0).
- * The pointers belong to the library and are valid until the submit. */
+ * The pointers belong to the library and are valid until the submit (or the release); sitrk_alloc_records and
+ * sitrk_destroy free the buffers, so nothing handed out before them may be touched afterwards.
+ * sitrk_stage_release gives an acquired buffer back WITHOUT uploading it (a reader that failed half-way): the next
+ * acquire hands out the same buffer again.  Releasing when nothing is acquired is not an error. */
 int   sitrk_stage_acquire(sitrk_t *h, int nrows, void **u, void **v, void **sic);
 int   sitrk_stage_submit(sitrk_t *h, int slot, int j0, int j1);
+int   sitrk_stage_release(sitrk_t *h);
 int   sitrk_push_record_dev(sitrk_t *h, int slot, const void *slab_dev);                        /* device pointer: [u|v|sic] */
 void *sitrk_record_ptr(sitrk_t *h, int slot);   /* device address of a slot's slab (broadcast target); NULL on error */
 /* A slot whose slab was (re)written in place through sitrk_record_ptr must be committed before it is

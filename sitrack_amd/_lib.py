@@ -39,6 +39,7 @@ _SIGNATURES = {
     "sitrk_push_record_dev": (_int, [_vp, _int, _vp]),
     "sitrk_stage_acquire": (_int, [_vp, _int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "sitrk_stage_submit": (_int, [_vp, _int, _int, _int]),
+    "sitrk_stage_release": (_int, [_vp]),
     "sitrk_launch_stats": (_int, [_vp, _int, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "sitrk_buoy_rows": (_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sitrk_push_record_rows": (_int, [_vp, _int, _int, _int, _vp, _vp, _vp]),
@@ -225,8 +226,10 @@ class Context:
         self._chk(self._L.sitrk_push_record(self._h, int(slot), _ptr(u), _ptr(v), _ptr(sic)))
 
     def stage(self, nrows=None):
-        """The library's next pinned staging buffer as three (nrows, Ni) arrays of the records' dtype (views of pinned
-        host memory, valid until submit()): read the record straight into them, then submit(slot, j0)."""
+        """The library's next pinned staging buffer as three (nrows, Ni) arrays of the records' dtype: read the record
+        straight into them, then submit(slot, j0).  The arrays are VIEWS of pinned host memory the library owns: valid
+        until submit() / stage_release(), and dangling after alloc_records(), set_grid() or close(), which free it.
+        Prefer stage_fill(), which also releases the buffer when the read fails."""
         nrows = self.Nj if nrows is None else int(nrows)
         pu, pv, ps = _vp(), _vp(), _vp()
         self._chk(self._L.sitrk_stage_acquire(self._h, nrows, C.byref(pu), C.byref(pv), C.byref(ps)))
@@ -236,6 +239,24 @@ class Context:
             return np.frombuffer((C.c_char * nb).from_address(p.value), dtype=self.field_dtype).reshape(nrows, self.Ni)
         self._staged_rows = nrows
         return view(pu), view(pv), view(ps)
+
+    def stage_release(self):
+        """Give the buffer handed out by stage() back without uploading it (the read into it failed): the views must not
+        be used any more, the next stage() hands out the same buffer."""
+        self._chk(self._L.sitrk_stage_release(self._h))
+
+    def stage_fill(self, slot, j0, nrows, fill):
+        """stage() + fill(u, v, sic) + submit(slot, j0), exception safe: if `fill` raises, the buffer is released, so the
+        context stays usable (a later stage()/push_record is not refused with 'not submitted')."""
+        bufs = self.stage(nrows)
+        try:
+            fill(*bufs)
+        except BaseException:
+            self.stage_release()
+            raise
+        finally:
+            del bufs                                     # the views die with the hand-out
+        self.submit(slot, j0)
 
     def submit(self, slot, j0=0):
         """Queue the staged rows as rows [j0, j0+nrows) of `slot` (asynchronous, see sitrk_stage_submit)."""

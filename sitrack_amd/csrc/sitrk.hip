@@ -73,7 +73,7 @@ static void free_buoys(sitrk_ctx *h)
 {
     for (int b = 0; b < 2; b++) {
         dev_free(h->st[b].pos); dev_free(h->st[b].cell); dev_free(h->st[b].kill_rec);
-        dev_free(h->st[b].first); dev_free(h->st[b].last); dev_free(h->st[b].perm);
+        dev_free(h->st[b].win); dev_free(h->st[b].perm);
         h->st[b] = BuoyState();
         dev_free(h->keys[b]); dev_free(h->vals[b]);
         h->keys[b] = nullptr; h->vals[b] = nullptr;
@@ -347,26 +347,15 @@ static int derive_mask_rows(sitrk_ctx *h, int slot, int j0, int j1, int v0, int 
     int8_t *kill = h->kill + (size_t)slot * n;
     int rc = slot_wait_upload(h, slot);
     if (rc) return rc;
-    if (j0 == 0 && j1 == h->Nj && v0 == 0 && v1 == h->Nj) {
-        if (h->dtype == SITRK_F64)
-            hipLaunchKernelGGL((survive_mask_kernel<double>), dim3(nblocks((int64_t)n)), dim3(kBlock), 0, h->stream, h->Nj, h->Ni, h->tmask,
-                               (const double *)sic, h->rmin_conc, kill);
-        else
-            hipLaunchKernelGGL((survive_mask_kernel<float>), dim3(nblocks((int64_t)n)), dim3(kBlock), 0, h->stream, h->Nj, h->Ni, h->tmask,
-                               (const float *)sic, h->rmin_conc, kill);
-    } else {
-        const int64_t cells = (int64_t)(j1 - j0) * h->Ni;
-        if (h->dtype == SITRK_F64)
-            hipLaunchKernelGGL((survive_mask_rows_kernel<double>), dim3(nblocks(cells)), dim3(kBlock), 0, h->stream, h->Nj, h->Ni, j0, j1, v0, v1,
-                               h->tmask, (const double *)sic, h->rmin_conc, kill);
-        else
-            hipLaunchKernelGGL((survive_mask_rows_kernel<float>), dim3(nblocks(cells)), dim3(kBlock), 0, h->stream, h->Nj, h->Ni, j0, j1, v0, v1,
-                               h->tmask, (const float *)sic, h->rmin_conc, kill);
-    }
-    HIPCHK(hipGetLastError());
-    // the 3x3 neighbourhoods of those bytes, one word per cell, for the fused kernel
-    hipLaunchKernelGGL(pack_kill9_kernel, dim3(nblocks((int64_t)(j1 - j0) * h->Ni)), dim3(kBlock), 0, h->stream, h->Nj, h->Ni, j0, j1, v0, v1,
-                       kill, h->kill9 + (size_t)slot * n);
+    // one pass: the Survive bytes of these rows and the 3x3 neighbourhoods of them, one byte per cell, for the fused kernel
+    const dim3 grid((unsigned)((h->Ni + kSvTC - 1) / kSvTC), (unsigned)((j1 - j0 + kSvTR - 1) / kSvTR));
+    uint8_t *kill9 = h->kill9 + (size_t)slot * n;
+    if (h->dtype == SITRK_F64)
+        hipLaunchKernelGGL((survive_kill9_kernel<double>), grid, dim3(kSvBlock), 0, h->stream, h->Nj, h->Ni, j0, j1, v0, v1, h->tmask,
+                           (const double *)sic, h->rmin_conc, kill, kill9);
+    else
+        hipLaunchKernelGGL((survive_kill9_kernel<float>), grid, dim3(kSvBlock), 0, h->stream, h->Nj, h->Ni, j0, j1, v0, v1, h->tmask,
+                           (const float *)sic, h->rmin_conc, kill, kill9);
     HIPCHK(hipGetLastError());
     h->slot_dirty[slot] = 0;
     return SITRK_OK;
@@ -436,6 +425,13 @@ SITRK_API int sitrk_stage_submit(sitrk_t *h, int slot, int j0, int j1)
     int rc = derive_mask_rows(h, slot, j0, j1, j0, j1);
     if (rc) return rc;
     return launch_mark(h, &slot, 1);    // that kernel reads the slot's siconc: a later upload into the slot stays behind it
+}
+
+SITRK_API int sitrk_stage_release(sitrk_t *h)
+{
+    NEED(h, "null handle");
+    h->stage_rows = -1;                 // stage_next is unchanged: the same buffer goes out again
+    return SITRK_OK;
 }
 
 static int push_rows(sitrk_ctx *h, int slot, int j0, int j1, const void *u, const void *v, const void *sic)
@@ -588,19 +584,26 @@ SITRK_API int sitrk_set_buoys(sitrk_t *h, int64_t nP, const double *yx, const in
     }
     h->rim_buoys = rim;
     h->win_first_max = INT32_MIN; h->win_last_min = INT32_MAX;
-    if (h->windowed)
+    std::vector<int2> win;                          // (first, last) interleaved: one 8-byte word per buoy on the device
+    if (h->windowed) {
+        try {
+            win.resize((size_t)nP);
+        } catch (const std::bad_alloc &) {
+            return fail(h, SITRK_ENOMEM, "sitrk_set_buoys: out of host memory for %lld buoys", (long long)nP);
+        }
         for (int64_t p = 0; p < nP; p++) {
             h->win_first_max = std::max(h->win_first_max, rec_first[p]);
             h->win_last_min = std::min(h->win_last_min, rec_last[p]);
+            win[(size_t)p].x = rec_first[p]; win[(size_t)p].y = rec_last[p];
         }
+    }
     for (int b = 0; b < 2; b++) {
         HIPCHK(dev_alloc(&h->st[b].pos, (size_t)nP));
         HIPCHK(dev_alloc(&h->st[b].cell, (size_t)nP));
         HIPCHK(dev_alloc(&h->st[b].kill_rec, (size_t)nP));
         HIPCHK(dev_alloc(&h->st[b].perm, (size_t)nP));
         if (h->windowed) {
-            HIPCHK(dev_alloc(&h->st[b].first, (size_t)nP));
-            HIPCHK(dev_alloc(&h->st[b].last, (size_t)nP));
+            HIPCHK(dev_alloc(&h->st[b].win, (size_t)nP));
         }
         HIPCHK(dev_alloc(&h->keys[b], (size_t)nP));
         HIPCHK(dev_alloc(&h->vals[b], (size_t)nP));
@@ -614,8 +617,7 @@ SITRK_API int sitrk_set_buoys(sitrk_t *h, int64_t nP, const double *yx, const in
     hipLaunchKernelGGL(iota_kernel, dim3(nblocks(nP)), dim3(kBlock), 0, h->stream, nP, s.perm);
     HIPCHK(hipGetLastError());
     if (h->windowed) {
-        HIPCHK(hipMemcpyAsync(s.first, rec_first, (size_t)nP * 4, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(s.last, rec_last, (size_t)nP * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(s.win, win.data(), (size_t)nP * sizeof(int2), hipMemcpyHostToDevice, h->stream));
     }
     HIPCHK(hipStreamSynchronize(h->stream));      // `packed` must outlive the copy
     return SITRK_OK;
@@ -686,7 +688,8 @@ SITRK_API int sitrk_sort_buoys(sitrk_t *h)
     }
     size_t tb = h->sort_tmp_bytes;
     HIPCHK(sort_pairs_u32(h->sort_tmp, &tb, h->keys[0], h->keys[1], h->vals[0], h->vals[1], (size_t)nP, end_bit, h->stream));
-    hipLaunchKernelGGL(permute_state_kernel, dim3(nblocks(nP)), dim3(kBlock), 0, h->stream, nP, h->vals[1], in, out, h->windowed);
+    hipLaunchKernelGGL(permute_state_kernel, dim3(nblocks(nP)), dim3(kBlock), 0, h->stream, nP, h->vals[1], h->keys[1], dead_key, h->Ni, h->tile_j, h->tile_i,
+                       in, out, h->windowed);
     HIPCHK(hipGetLastError());
     h->cur ^= 1;
     h->sorted_once = true;
@@ -756,7 +759,7 @@ SITRK_API int sitrk_step(sitrk_t *h, int slot, int jrec)
     a.rdt = h->rdt; a.rmin_conc = h->rmin_conc; a.eps_mg = h->eps_mg;
     a.geo = h->geo; a.orient = h->orient; a.kill = h->kill + (size_t)slot * n;
     a.u = slab; a.v = slab + n * es;
-    a.pos = s.pos; a.cell = s.cell; a.kill_rec = s.kill_rec; a.first = s.first; a.last = s.last;
+    a.pos = s.pos; a.cell = s.cell; a.kill_rec = s.kill_rec; a.win = s.win;
     if (h->dtype == SITRK_F64) launch_step<double>(h, a);
     else launch_step<float>(h, a);
     HIPCHK(hipGetLastError());
@@ -832,7 +835,7 @@ SITRK_API int sitrk_run(sitrk_t *h, int slot0, int jrec0, int nsteps)
         RunArgs ra;
         ra.s.nP = h->nP; ra.s.tune = h->tune; ra.s.Nj = h->Nj; ra.s.Ni = h->Ni; ra.s.jrec = jrec0 + k;
         ra.s.rdt = h->rdt; ra.s.rmin_conc = h->rmin_conc; ra.s.eps_mg = h->eps_mg; ra.s.geo = h->geo; ra.s.orient = h->orient; ra.s.kill = nullptr; ra.s.u = ra.s.v = nullptr;
-        ra.s.pos = s.pos; ra.s.cell = s.cell; ra.s.kill_rec = s.kill_rec; ra.s.first = s.first; ra.s.last = s.last;
+        ra.s.pos = s.pos; ra.s.cell = s.cell; ra.s.kill_rec = s.kill_rec; ra.s.win = s.win;
         ra.nrec = m;
         make_cross_tab(h->Ni, ra.tab, ra.dji);
         ra.geoF = h->geoF;
@@ -1272,12 +1275,14 @@ SITRK_API int sitrk_survive_mask(sitrk_t *h, const double *sic, int8_t *mask)
     HIPCHK(hipSetDevice(h->device));
     const size_t cells = (size_t)h->Nj * h->Ni;
     const size_t b_s = align256(cells * 8), b_m = align256(cells);
-    int rc = ensure_scratch(h, b_s + b_m);
+    int rc = ensure_scratch(h, b_s + 2 * b_m);
     if (rc) return rc;
     char *s = (char *)h->scratch;
     HIPCHK(hipMemcpyAsync(s, sic, cells * 8, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL((survive_mask_kernel<double>), dim3(nblocks((int64_t)cells)), dim3(kBlock), 0, h->stream, h->Nj, h->Ni, h->tmask,
-                       (const double *)s, h->rmin_conc, (int8_t *)(s + b_s));
+    // the very kernel that derives a resident record's bytes (the packed neighbourhoods go to scratch and are dropped)
+    hipLaunchKernelGGL((survive_kill9_kernel<double>), dim3((unsigned)((h->Ni + kSvTC - 1) / kSvTC), (unsigned)((h->Nj + kSvTR - 1) / kSvTR)),
+                       dim3(kSvBlock), 0, h->stream, h->Nj, h->Ni, 0, h->Nj, 0, h->Nj, h->tmask, (const double *)s, h->rmin_conc,
+                       (int8_t *)(s + b_s), (uint8_t *)(s + b_s + b_m));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(mask, s + b_s, cells, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));

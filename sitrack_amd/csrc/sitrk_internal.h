@@ -17,8 +17,8 @@ struct BuoyState {
     pt      *pos      = nullptr;   // (y,x) km, current position           16 B
     int32_t *cell     = nullptr;   // packed (jT,iT) | dead bit              4 B
     int32_t *kill_rec = nullptr;   // model record of the kill, -1 alive     4 B
-    int32_t *first    = nullptr;   // z1stModelRec (only when windowed)      4 B
-    int32_t *last     = nullptr;   // zLstModelRec                           4 B
+    int2    *win      = nullptr;   // (z1stModelRec, zLstModelRec), only when windowed: one 8-byte word, so that the
+                                   // re-sort gathers it with one request                          8 B
     int32_t *perm     = nullptr;   //                                        4 B
 };
 

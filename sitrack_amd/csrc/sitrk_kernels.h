@@ -71,67 +71,110 @@ __device__ __forceinline__ bool survive_kill(int jT, int iT, int Nj, int Ni, con
 }
 
 // ---------------------------------------------------------------------------
-// Per-record Survive mask.  `Survive` (tracking.py:62-93) depends only on the cell and on the
-// record's ice concentration, so it is evaluated ONCE PER CELL when a record becomes resident
-// (same tests, same order, same left-to-right fp64 sum) and the crossing path reads one byte
-// instead of chasing two dependent 5-point stencils through memory.
+// Per-record Survive bytes, ONE pass over a record (or over an uploaded row band).  `Survive` (tracking.py:62-93)
+// depends only on the cell and on the record's ice concentration, so it is evaluated ONCE PER CELL when a record
+// becomes resident (same tests, same order, same left-to-right fp64 sum) and the crossing path reads one byte instead
+// of chasing two dependent 5-point stencils through memory.  Two outputs per cell:
+//   kill [j,i]  the Survive byte itself (the one-record kernel's crossing path reads three of them);
+//   kill9[j,i]  the Survive bytes of the cell's 8 neighbours, bit b = cell (j+dj, i+di) with (dj+1)*3 + (di+1) = b for
+//               b < 4 and b + 1 otherwise (the centre is never a destination): the fused kernel requests this ONE byte
+//               per buoy and record together with the velocities, at the top of a record's iteration, not behind the
+//               crossing test -- it is the one crossing-path operand that is new with every record, i.e. never in cache.
+// A workgroup owns a tile of 32 x 64 cells: the tile's siconc and tmask with a halo of two cells go to LDS by row-wise
+// coalesced loads, the Survive bytes of the tile and a halo of one cell are evaluated from LDS into LDS, and every
+// thread then packs strips of four cells (one 32-bit store per output).  Rows: [j_lo, j_hi) are written, of which the
+// siconc rows [v_lo, v_hi) are valid (row-band ingest; the whole record: 0, Nj, 0, Nj).  A Survive byte is derived
+// when its 3-row stencil is valid or when its row belongs to the domain rim (killed whatever the ice is: slots are
+// born with "kill" everywhere), else it is left alone; a kill9 byte whose three byte rows are not all derivable gets
+// the sentinel "everything kills".
+// (round 2 did this in two passes, survive_mask_kernel + pack_kill9_kernel: 58 + 52 us per 4096^2 record.)
 // ---------------------------------------------------------------------------
-template <typename FT>
-__global__ void survive_mask_kernel(int Nj, int Ni, const int8_t *__restrict__ tmask, const FT *__restrict__ sic,
-                                    double rmin_conc, int8_t *__restrict__ kill)
-{
-    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= (size_t)Nj * Ni) return;
-    const int j = (int)(k / (size_t)Ni), i = (int)(k % (size_t)Ni);
-    kill[k] = survive_kill<FT>(j, i, Nj, Ni, tmask, sic, rmin_conc) ? 1 : 0;
-}
+static constexpr int kSvTR = 32, kSvTC = 64;                   // cells per workgroup
+static constexpr int kSvSC = kSvTC + 4, kSvSR = kSvTR + 4;     // siconc / tmask tile: halo of 2 (two nested 3-row stencils)
+static constexpr int kSvKC = kSvTC + 2, kSvKR = kSvTR + 2;     // Survive bytes: halo of 1
+static constexpr int kSvKP = 72;                               // their row pitch in LDS: 8-byte aligned rows of 66 (+2 read past)
+static constexpr int kSvBlock = 256;
 
-// Same for the rows [j_lo, j_hi) only, of which the siconc rows [v_lo, v_hi) are valid: a row is derived when its
-// 3-row stencil is valid or when it belongs to the domain rim (killed whatever the ice is).  Row-band ingest.
 template <typename FT>
-__global__ void survive_mask_rows_kernel(int Nj, int Ni, int j_lo, int j_hi, int v_lo, int v_hi, const int8_t *__restrict__ tmask,
-                                         const FT *__restrict__ sic, double rmin_conc, int8_t *__restrict__ kill)
+__global__ __launch_bounds__(kSvBlock) void survive_kill9_kernel(int Nj, int Ni, int j_lo, int j_hi, int v_lo, int v_hi,
+                                                                const int8_t *__restrict__ tmask, const FT *__restrict__ sic,
+                                                                double rmin_conc, int8_t *__restrict__ kill, uint8_t *__restrict__ kill9)
 {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)(j_hi - j_lo) * Ni) return;
-    const int j = j_lo + (int)(t / (size_t)Ni), i = (int)(t % (size_t)Ni);
-    const bool rim = (j <= 1 || j >= Nj - 2);
-    if (!rim && (j - 1 < v_lo || j + 1 >= v_hi)) return;      // stencil not inside the uploaded rows: leave the byte alone
-    kill[(size_t)j * Ni + i] = survive_kill<FT>(j, i, Nj, Ni, tmask, sic, rmin_conc) ? 1 : 0;
-}
-
-// The fused kernel reads ONE byte per buoy and record instead of three Survive bytes at computed addresses per crossing:
-// the Survive bytes of the 8 neighbours of cell (j,i), bit b of kill9[j,i] = cell (j+dj, i+di) with (dj+1)*3 + (di+1) = b
-// for b < 4 and b + 1 otherwise (the centre is never a destination).  It is requested together with the record's velocities,
-// at the top of a record's iteration, not behind the crossing test: it is the one crossing-path operand that is new with
-// every record, i.e. never in cache.  Packed from the byte mask for rows [j_lo, j_hi);
-// a row whose three byte rows are not all valid (valid = domain rim, or inside (v_lo, v_hi-1): see
-// survive_mask_rows_kernel) gets the sentinel "everything kills".
-__global__ void pack_kill9_kernel(int Nj, int Ni, int j_lo, int j_hi, int v_lo, int v_hi, const int8_t *__restrict__ kill,
-                                  uint8_t *__restrict__ kill9)
-{
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)(j_hi - j_lo) * Ni) return;
-    const int j = j_lo + (int)(t / (size_t)Ni), i = (int)(t % (size_t)Ni);
-    unsigned w = 0xffu;
-    bool ok = (j >= 1 && j <= Nj - 2 && i >= 1 && i <= Ni - 2);
-    for (int dj = -1; dj <= 1 && ok; dj++) {
-        const int r = j + dj;
-        const bool rim = (r <= 1 || r >= Nj - 2);
-        ok = rim || (r - 1 >= v_lo && r + 1 < v_hi);
+    __shared__ FT s_sic[kSvSR * kSvSC];
+    __shared__ int8_t s_tm[kSvSR * kSvSC];
+    __shared__ __attribute__((aligned(8))) uint8_t s_k[kSvKR * kSvKP];
+    const int jt0 = j_lo + (int)blockIdx.y * kSvTR, it0 = (int)blockIdx.x * kSvTC;
+    // ---- the tile's inputs, halo of 2, row-wise coalesced; outside the mesh: anything (such cells are rim or beyond)
+    for (int t = threadIdx.x; t < kSvSR * kSvSC; t += kSvBlock) {
+        const int r = t / kSvSC, c = t - r * kSvSC;
+        const int j = jt0 - 2 + r, i = it0 - 2 + c;
+        const bool in = (j >= 0) & (j < Nj) & (i >= 0) & (i < Ni);
+        const size_t k = (size_t)(in ? j : 0) * Ni + (in ? i : 0);
+        s_sic[t] = sic[k];
+        s_tm[t] = tmask[k];
     }
-    if (ok) {
-        w = 0;
-        const size_t k = (size_t)j * Ni + i;
-#pragma unroll
-        for (int dj = -1; dj <= 1; dj++)
-#pragma unroll
-            for (int di = -1; di <= 1; di++) {
-                const int b9 = (dj + 1) * 3 + (di + 1);
-                if (b9 != 4) w |= (kill[k + (ptrdiff_t)dj * Ni + di] ? 1u : 0u) << (b9 < 4 ? b9 : b9 - 1);
+    __syncthreads();
+    // ---- Survive (tracking.py:62-93) for the tile and a halo of 1; true = kill
+    for (int t = threadIdx.x; t < kSvKR * kSvKC; t += kSvBlock) {
+        const int r = t / kSvKC, c = t - r * kSvKC;
+        const int j = jt0 - 1 + r, i = it0 - 1 + c;
+        bool kl = true;                                                              // too close to the domain boundaries (:73)
+        if (!(j <= 1 || j >= Nj - 2 || i <= 1 || i >= Ni - 2)) {
+            const int s = (r + 1) * kSvSC + (c + 1);
+            // land-sea mask, 5 points; note [j-1,i-1] (:79)
+            const int zmt = (int)s_tm[s] + (int)s_tm[s + 1] + (int)s_tm[s + kSvSC] + (int)s_tm[s - 1] + (int)s_tm[s - kSvSC - 1];
+            kl = zmt < 5;
+            if (!kl) {
+                // sea-ice concentration, same stencil, summed left to right in fp64 (:87-89)
+                const double zic = 0.2 * ((double)s_sic[s] + (double)s_sic[s + 1] + (double)s_sic[s + kSvSC] + (double)s_sic[s - 1] +
+                                          (double)s_sic[s - kSvSC - 1]);
+                kl = zic < rmin_conc;
             }
+        }
+        s_k[r * kSvKP + c] = kl ? 1 : 0;
     }
-    kill9[(size_t)j * Ni + i] = (uint8_t)w;
+    __syncthreads();
+    // ---- strips of four cells: their Survive bytes and the packed neighbourhoods
+    const bool vec = (Ni & 3) == 0;                                                  // rows are 4-byte aligned: one store per strip
+    for (int g = threadIdx.x; g < kSvTR * (kSvTC / 4); g += kSvBlock) {
+        const int r = g / (kSvTC / 4), c4 = (g - r * (kSvTC / 4)) * 4;
+        const int j = jt0 + r, i0 = it0 + c4;
+        if (j >= j_hi || i0 >= Ni) continue;
+        // byte rows j-1, j, j+1, columns i0-1 .. i0+4 (bytes 0..5 of each word; 6, 7 unused)
+        // (two 4-byte aligned words each)
+        const uint32_t *p0 = (const uint32_t *)&s_k[r * kSvKP + c4], *p1 = p0 + kSvKP / 4, *p2 = p1 + kSvKP / 4;
+        const uint64_t R0 = p0[0] | ((uint64_t)p0[1] << 32), R1 = p1[0] | ((uint64_t)p1[1] << 32), R2 = p2[0] | ((uint64_t)p2[1] << 32);
+        // which byte rows can be derived from the rows that were uploaded (the rim rows always can)
+        bool ok3 = (j >= 1) & (j <= Nj - 2);
+#pragma unroll
+        for (int dj = -1; dj <= 1; dj++) {
+            const int rr = j + dj;
+            ok3 = ok3 & ((rr <= 1) | (rr >= Nj - 2) | ((rr - 1 >= v_lo) & (rr + 1 < v_hi)));
+        }
+        const bool wr_kill = (j <= 1) | (j >= Nj - 2) | ((j - 1 >= v_lo) & (j + 1 < v_hi));
+        unsigned w9 = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const unsigned a = (unsigned)(R0 >> (8 * q)) & 0x010101u, b = (unsigned)(R1 >> (8 * q)) & 0x010001u,
+                           c = (unsigned)(R2 >> (8 * q)) & 0x010101u;
+            unsigned w = (a & 1u) | ((a >> 7) & 2u) | ((a >> 14) & 4u) | ((b & 1u) << 3) | ((b >> 12) & 16u) |
+                         ((c & 1u) << 5) | ((c >> 2) & 64u) | ((c >> 9) & 128u);
+            const int i = i0 + q;
+            if (!(ok3 && i >= 1 && i <= Ni - 2)) w = 0xffu;
+            w9 |= w << (8 * q);
+        }
+        const unsigned wk = (unsigned)(R1 >> 8);                                      // the strip's own four Survive bytes
+        const size_t k = (size_t)j * Ni + i0;
+        if (vec) {
+            if (wr_kill) *(unsigned *)(kill + k) = wk;
+            *(unsigned *)(kill9 + k) = w9;
+        } else {
+            for (int q = 0; q < 4 && i0 + q < Ni; q++) {
+                if (wr_kill) kill[k + q] = (int8_t)((wk >> (8 * q)) & 0xffu);
+                kill9[k + q] = (uint8_t)((w9 >> (8 * q)) & 0xffu);
+            }
+        }
+    }
 }
 
 // rows of the host cells of the buoys that are still alive: out[0] = min jT, out[1] = max jT
@@ -380,7 +423,7 @@ struct StepArgs {
     pt *pos;
     int32_t *cell;
     int32_t *kill_rec;
-    const int32_t *first, *last;
+    const int2 *win;                    // per-buoy (first, last) model record, 2-D time mode only
 };
 
 // ---------------------------------------------------------------------------
@@ -452,7 +495,8 @@ __global__ __launch_bounds__(BLOCK, 8) void advect_step_kernel(StepArgs a)
     int32_t c = nt ? __builtin_nontemporal_load(&a.cell[p]) : a.cell[p];
     if (c < 0) return;                                   // iAlive != 1 (:380)
     if (WINDOW) {
-        if (a.jrec < a.first[p] || a.jrec > a.last[p]) return;
+        const int2 w = a.win[p];
+        if (a.jrec < w.x || a.jrec > w.y) return;
     }
     pt P = nt ? load_pt_nt(&a.pos[p]) : a.pos[p];        // (ry, rx)
     const int32_t c0 = c;
@@ -682,7 +726,7 @@ __global__ __launch_bounds__(kRunBlock, WINDOW ? SITRK_RUN_WAVES_WINDOW : SITRK_
     __syncthreads();                                     // last barrier: from here on lanes may leave
     if (!live) return;
     int first = 0, last = 0x7fffffff;
-    if (WINDOW) { first = a.first[p]; last = a.last[p]; }
+    if (WINDOW) { const int2 w = a.win[p]; first = w.x; last = w.y; }
     pt P = nt ? load_pt_nt(&a.pos[p]) : a.pos[p];
     bool moved = false, recelled = false;               // (lane flags: the cell is stored only if it changed)
     CellCtx x;
@@ -960,18 +1004,38 @@ __global__ void make_keys_kernel(int64_t n, int Ni, int tj, int ti, uint32_t dea
     vals[s] = (int32_t)s;
 }
 
-__global__ void permute_state_kernel(int64_t n, const int32_t *__restrict__ src, BuoyState in, BuoyState out, bool windowed)
+// inverse of cell_key
+__host__ __device__ __forceinline__ int32_t cell_of_key(uint32_t key, int Ni, int tj, int ti)
+{
+    if (tj == 0) return pack_cell((int)(key / (uint32_t)Ni), (int)(key % (uint32_t)Ni));
+    const uint32_t nti = ((uint32_t)Ni + (uint32_t)ti - 1u) / (uint32_t)ti, tcells = (uint32_t)(tj * ti);
+    const uint32_t tile = key / tcells, w = key - tile * tcells;
+    const uint32_t jt = tile / nti, it = tile - jt * nti, jr = w / (uint32_t)ti, ir = w - jr * (uint32_t)ti;
+    return pack_cell((int)(jt * (uint32_t)tj + jr), (int)(it * (uint32_t)ti + ir));
+}
+
+// The re-sort's tail: slot s of the new order takes the state of slot src[s] of the old one.  A gather costs one 64-byte
+// fabric request per array whatever it needs of it (measured on the first sort of a random set: 4.0 requests per buoy for
+// pos, cell, kill_rec, perm = 2.5 GB for 280 MB of state, 766 us), so as few arrays as possible are gathered:
+//   the host cell IS the sorted key (cell_of_key), the kill record of a live buoy is -1 by definition -- only dead
+//   buoys (key == dead_key, the tail of the order) gather those two; the record window is one 8-byte word.
+// Left: pos and perm (+ win): 2 (3) requests per buoy instead of 4 (6).
+__global__ void permute_state_kernel(int64_t n, const int32_t *__restrict__ src, const uint32_t *__restrict__ skeys, uint32_t dead_key,
+                                     int Ni, int tj, int ti, BuoyState in, BuoyState out, bool windowed)
 {
     int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
-    int32_t q = src[s];
+    const int32_t q = src[s];
+    const uint32_t key = skeys[s];
     out.pos[s] = in.pos[q];
-    out.cell[s] = in.cell[q];
-    out.kill_rec[s] = in.kill_rec[q];
     out.perm[s] = in.perm[q];
-    if (windowed) {
-        out.first[s] = in.first[q];
-        out.last[s] = in.last[q];
+    if (windowed) out.win[s] = in.win[q];
+    if (key == dead_key) {
+        out.cell[s] = in.cell[q];
+        out.kill_rec[s] = in.kill_rec[q];
+    } else {
+        out.cell[s] = cell_of_key(key, Ni, tj, ti);
+        out.kill_rec[s] = -1;
     }
 }
 
@@ -1014,7 +1078,7 @@ __global__ void fetch_record_kernel(int64_t n, int jrec, BuoyState st, bool wind
     int32_t o = st.perm[s];
     int32_t c = st.cell[s];
     bool in_window = true;
-    if (windowed) in_window = (jrec >= st.first[s]) && (jrec <= st.last[s]);
+    if (windowed) { const int2 w = st.win[s]; in_window = (jrec >= w.x) && (jrec <= w.y); }
     // stepped at jrec  <=>  was alive before it: still alive, or killed by this very record
     bool stepped = in_window && (c >= 0 || st.kill_rec[s] == jrec);
     if (yx) yx[o] = stepped ? st.pos[s] : make_pt(-9999.0, -9999.0);      // sitrack/ncio.py:19 FillValue

@@ -186,7 +186,14 @@ class RecordBroadcaster:
                 n = self.ctx.Nj * self.ctx.Ni
                 host = self.pinned[b].numpy()
                 for f, a in enumerate(fields):
-                    host[f * n:(f + 1) * n] = np.asarray(a).reshape(-1)
+                    a = np.asarray(a)
+                    # the slot's dtype is the context's; a field of another type must survive the cast exactly, as in
+                    # IceTracker.load_record / RecordReader.fields_rows_into (an f8 siconc next to f4 velocities would
+                    # otherwise be rounded silently)
+                    if a.dtype.newbyteorder('=') != host.dtype and not np.array_equal(a.astype(host.dtype).astype(a.dtype), a, equal_nan=True):
+                        raise ValueError("%s is not exactly representable as %s; allocate float64 records"
+                                         % (("u_ice", "v_ice", "siconc")[f], host.dtype))
+                    host[f * n:(f + 1) * n] = a.reshape(-1)
                 self.slots[slot].copy_(self.pinned[b], non_blocking=True)
                 self.pin_done[b].record(self.comm)
                 self.npush += 1

@@ -373,13 +373,11 @@ def main(argv=None):
             jrec, slot = jt0 + r + kstrt, (jt0 + r) % K
             if not a.full_records:
                 if j1 > j0:
-                    records.fields_rows_into(jrec, j0, j1, ctx.stage(j1 - j0))
-                    ctx.submit(slot, j0)
+                    ctx.stage_fill(slot, j0, j1 - j0, lambda *outs: records.fields_rows_into(jrec, j0, j1, outs))
                 else:
                     ctx.commit_record_rows(slot, 0, 0)                  # no live buoy: nothing to read
             elif comm.world == 1:
-                records.fields_rows_into(jrec, 0, Nj, ctx.stage(Nj))   # the whole record (:372-374)
-                ctx.submit(slot, 0)
+                ctx.stage_fill(slot, 0, Nj, lambda *outs: records.fields_rows_into(jrec, 0, Nj, outs))   # the whole record (:372-374)
             elif bcast is not None:
                 bcast.deliver(slot, records.fields(jrec) if comm.root else None)
             else:

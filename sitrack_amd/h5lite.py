@@ -368,6 +368,7 @@ class NC4Writer:
         L.H5Pclose(fcpl)
         if self.fid < 0:
             raise OSError("H5Fcreate(%s) failed" % path)
+        self.path = path
         self.dims = {}                   # name -> (size, unlimited, dimid)
         self.vars = {}                   # name -> (hid, dtype key, dim names)
 
@@ -479,10 +480,15 @@ class NC4Writer:
         for r in range(nrec):
             for c0 in range(0, n, cw):
                 self._pending.append((d, r, c0, self._pool.submit(pack, r, c0)))
+        # every queued job keeps its variable's array alive: bound what waits (10^8 buoys x 2 records x 6 variables = 4.8 GB)
+        self._pending_bytes = getattr(self, "_pending_bytes", 0) + a.nbytes
+        if self._pending_bytes > int(os.environ.get("SITRK_NC_PENDING_BYTES", str(4 << 30))):
+            self.flush()
 
     def flush(self):
         """hand the queued chunks to libhdf5 (in the order they were queued; the calls themselves are serial)"""
         pending, self._pending = getattr(self, "_pending", []), []
+        self._pending_bytes = 0
         try:
             for d, r, c0, fut in pending:
                 blob = fut.result()
@@ -493,31 +499,56 @@ class NC4Writer:
             for _, _, _, fut in pending:
                 fut.cancel()
 
+    def _release(self):
+        """close every id this writer holds, whatever state the file is in"""
+        L = self.L
+        if getattr(self, "_pool", None) is not None:
+            for _, _, _, fut in getattr(self, "_pending", []):
+                fut.cancel()
+            self._pending = []
+            self._pool.shutdown(wait=True)
+            self._pool = None
+        for vid, _, _ in self.vars.values():
+            L.H5Dclose(vid)
+        self.vars = {}
+        if self.fid >= 0:
+            L.H5Fclose(self.fid)
+        self.fid = -1
+
+    def abort(self):
+        """Give up on the file: ids closed, the partial file removed.  For `except` blocks -- never raises, so the
+        exception that led here stays the one the caller sees."""
+        try:
+            self._release()
+        except Exception:               # noqa: BLE001
+            self.fid = -1
+        try:
+            os.remove(self.path)
+        except OSError:
+            pass
+
     def close(self):
-        """Turn the coordinate variables into dimension scales, attach every variable to its scales, close."""
+        """Turn the coordinate variables into dimension scales, attach every variable to its scales, close.  If any of
+        that fails the ids are closed all the same, the half-written file is removed and the error is raised."""
         if self.fid < 0:
             return
         L, H = self.L, self.H
         try:
             self.flush()
-        finally:
-            if getattr(self, "_pool", None) is not None:
-                self._pool.shutdown(wait=True)
-                self._pool = None
-        for dname, (size, unl, dimid) in self.dims.items():
-            if dname not in self.vars:
-                raise ValueError("dimension %s needs its coordinate variable" % dname)
-            did = self.vars[dname][0]
-            if H.H5DSset_scale(did, dname.encode()) < 0:
-                raise OSError("H5DSset_scale(%s) failed" % dname)
-            self._attr(did, "_Netcdf4Dimid", np.int32(dimid))
-        for vname, (vid, key, dims) in self.vars.items():
-            if vname in self.dims:
-                continue
-            for k, dname in enumerate(dims):
-                if H.H5DSattach_scale(vid, self.vars[dname][0], k) < 0:
-                    raise OSError("H5DSattach_scale(%s, %s) failed" % (vname, dname))
-        for vid, _, _ in self.vars.values():
-            L.H5Dclose(vid)
-        L.H5Fclose(self.fid)
-        self.fid = -1
+            for dname, (size, unl, dimid) in self.dims.items():
+                if dname not in self.vars:
+                    raise ValueError("dimension %s needs its coordinate variable" % dname)
+                did = self.vars[dname][0]
+                if H.H5DSset_scale(did, dname.encode()) < 0:
+                    raise OSError("H5DSset_scale(%s) failed" % dname)
+                self._attr(did, "_Netcdf4Dimid", np.int32(dimid))
+            for vname, (vid, key, dims) in self.vars.items():
+                if vname in self.dims:
+                    continue
+                for k, dname in enumerate(dims):
+                    if H.H5DSattach_scale(vid, self.vars[dname][0], k) < 0:
+                        raise OSError("H5DSattach_scale(%s, %s) failed" % (vname, dname))
+        except BaseException:
+            self.abort()
+            raise
+        self._release()

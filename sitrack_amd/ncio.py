@@ -447,6 +447,8 @@ def _save_nc4_hdf5(cf_out, ptime, pIDs, pY, pX, pLat, pLon, mask, xtime, tunits,
             w.set_global('Origin', corigin)
         w.set_global('About', about)
         w.set_global('Author', author)
-    finally:
-        w.close()
+    except BaseException:
+        w.abort()                       # ids closed, partial file removed; never raises: the original error is the one seen
+        raise
+    w.close()
     return 0

@@ -42,6 +42,9 @@ int main(void)
         void *pu, *pv, *ps;
         CHK(sitrk_stage_acquire(h, N, &pu, &pv, &ps));
         if (sitrk_stage_acquire(h, N, &pu, &pv, &ps) != SITRK_EINVAL) { printf("a second acquire without submit must be refused\n"); return 1; }
+        /* a reader that fails half-way gives the buffer back; the next acquire hands out the same one */
+        { void *qu = pu, *qv, *qs; CHK(sitrk_stage_release(h)); CHK(sitrk_stage_release(h)); CHK(sitrk_stage_acquire(h, N, &pu, &qv, &qs));
+          if (pu != qu) { printf("release must hand the same buffer out again\n"); return 1; } pv = qv; ps = qs; }
         for (int k = 0; k < N * N; k++) { ((float *)pu)[k] = 0.5f; ((float *)pv)[k] = -0.25f; ((float *)ps)[k] = 1.0f; }
         CHK(sitrk_stage_submit(h, 1, 0, N));
         /* rows 2..N-3 only into the third slot: stepping with it needs the buoys' band */

@@ -309,6 +309,16 @@ def test_bench_two_ranks_as_the_driver_launches_it():
     assert d["n_gpus"] == 2 and d["steps"] == 40 and d["warmup"] == 8 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["buoys_per_gpu"] == 100000 and "broadcast from rank 0" in d["config"]["records_via"]
     assert abs(d["value"] - 2 * 100000 * 40 / (d["ms_per_step"] * 40e-3)) < 1e-6 * d["value"]
+    # the line proves who took part and that the exchange delivered rank 0's bytes to every rank
+    rc = d["rccl"]
+    assert rc["world"] == 2 and rc["backend"] == "gloo" and [x["rank"] for x in rc["ranks"]] == [0, 1]
+    assert all(x["device"] == 0 and x["pid"] > 0 and "name" in x for x in rc["ranks"]) and rc["ranks"][0]["pid"] != rc["ranks"][1]["pid"]
+    assert rc["distinct_devices"] == 1                       # the rehearsal: both ranks on the box's one GPU
+    assert rc["slab_checksum_ok"] is True and rc["slab_checksum_matches_source"] is True
+    assert len(rc["slab_checksums"]) == 2 and rc["slab_checksums"][0] == rc["slab_checksums"][1] and len(rc["slab_checksum_slots"]) == 3
+    vr = rc["value_per_rank"]
+    assert len(vr["all"]) == 2 and 0 < vr["min"] <= vr["max"] and d["value"] <= 2 * vr["min"] * (1 + 1e-9)
+    assert "degraded" not in d
 
 
 @pytest.mark.gpu
@@ -328,6 +338,9 @@ def test_bench_multi_gpu_code_path_with_one_rccl_rank():
     assert "check OK" in r.stderr
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert "RCCL broadcast" in d["config"]["records_via"]
+    rc = d["rccl"]
+    assert rc["world"] == 1 and rc["backend"].startswith("rccl") and rc["ranks"][0]["rank"] == 0 and rc["distinct_devices"] == 1
+    assert rc["slab_checksum_ok"] is True and rc["slab_checksum_matches_source"] is True and "degraded" not in d
     e = d["e2e_broadcast"]
     assert "error" not in e, e
     for mode in ("broadcast", "scatter_allgather"):
@@ -338,7 +351,8 @@ def test_bench_multi_gpu_code_path_with_one_rccl_rank():
 @pytest.mark.gpu
 def test_bench_line_survives_a_stuck_end_to_end_segment():
     """The extra segment of `bench.py --gpus N` runs under a watchdog: when it does not come back in time (here: a wait of
-    a millisecond) rank 0 still prints the line with the resident numbers, the segment marked as timed out, exit code 0."""
+    a millisecond) rank 0 still prints the line with the resident numbers and the segment marked as timed out -- and the
+    process leaves with a NON-ZERO code (3): a stuck communicator must not look like a clean run."""
     import json
     import subprocess
     import sys
@@ -346,9 +360,89 @@ def test_bench_line_survives_a_stuck_end_to_end_segment():
     env = dict(os.environ, SITRK_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), SITRK_E2E_SEGMENT_TIMEOUT="0.001")
     r = subprocess.run([sys.executable, "bench.py", "--config", "c2", "--steps", "64", "--warmup", "8", "--no-cpu-baseline"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert r.returncode == 3, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
     assert "timed out" in d["e2e_broadcast"]["error"] and d["value"] > 0 and d["roofline"]["launches"] >= 2
+    assert d["rccl"]["slab_checksum_ok"] is True
+
+
+@pytest.mark.gpu
+def test_bench_broadcast_failure_is_visible_one_rccl_rank():
+    """A record broadcast that raises: no local regeneration behind the driver's back -- the line is printed with
+    "degraded" and value null, the exit code is 4."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SITRK_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), SITRK_BENCH_FAIL_BCAST="0")
+    r = subprocess.run([sys.executable, "bench.py", "--config", "c2", "--steps", "64", "--warmup", "8", "--no-cpu-baseline"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 4, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] is None and "record broadcast failed on rank 0" in d["degraded"] and d["phase"] == "record broadcast"
+    assert d["metric"] == "particle-steps/s" and d["n_gpus"] == 1 and d["config"]["workload"].startswith("C2")
+
+
+@pytest.mark.gpu
+def test_bench_broadcast_failure_on_another_rank_is_visible():
+    """Two ranks as the driver launches them (gloo on the one GPU); the broadcast fails on rank 1 only.  Rank 1 leaves
+    non-zero, the launcher terminates rank 0 -- which may sit inside the collective -- and rank 0 still prints ONE line
+    with "degraded" and value null; the launcher's exit code is non-zero."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SITRK_DIST_BACKEND="gloo", SITRK_DEVICE="0", SITRK_BENCH_FAIL_BCAST="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "40", "--warmup", "8", "--config", "c2",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["degraded"] and d["n_gpus"] == 2
+
+
+def _run_guard_script(body, env_extra=None, timeout=60):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = ("import os, sys, time, signal, json\nsys.path.insert(0, %r)\nimport bench\n"
+              "bench._STATE['multi'] = True\nbench._STATE['base'] = {'metric': 'particle-steps/s', 'value': None, 'n_gpus': 2}\n" % root) + body
+    env = dict(os.environ, **(env_extra or {}))
+    return subprocess.run([sys.executable, "-c", script], cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_guards_sigterm_prints_the_degraded_line():
+    """rank 0 terminated by the launcher while its main thread is busy in native code (here: a long sleep stands in for a
+    collective): the wake-up-pipe watcher prints the line and leaves with code 7."""
+    import json
+    r = _run_guard_script("bench._start_guards()\nbench._phase('record broadcast')\n"
+                          "os.kill(os.getpid(), signal.SIGTERM)\ntime.sleep(30)\nprint('not reached')\n")
+    assert r.returncode == 7, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and "not reached" not in r.stdout
+    d = json.loads(lines[0])
+    assert d["value"] is None and "SIGTERM" in d["degraded"] and d["phase"] == "record broadcast" and d["n_gpus"] == 2
+
+
+def test_bench_guards_no_progress_watchdog_and_single_line():
+    """a phase that never ends: the watchdog prints the line and leaves with code 6; ranks other than 0 print no line;
+    and the line is printed at most once however many paths reach _emit."""
+    import json
+    r = _run_guard_script("bench._start_guards()\nbench._phase('reductions')\ntime.sleep(30)\n", {"SITRK_BENCH_PHASE_TIMEOUT": "0.6"})
+    assert r.returncode == 6, r.stdout + r.stderr
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert "no progress" in d["degraded"] and d["phase"] == "reductions"
+    r = _run_guard_script("bench._STATE['rank'] = 1\nbench._start_guards()\ntime.sleep(30)\n", {"SITRK_BENCH_PHASE_TIMEOUT": "0.6"})
+    assert r.returncode == 6 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    r = _run_guard_script("assert bench._emit({'a': 1}) is True\nassert bench._emit({'a': 2}) is False\nbench._degraded_exit('x', 4)\n")
+    assert r.returncode == 4 and [l for l in r.stdout.splitlines() if l.startswith("{")] == ['{"a": 1}']
 
 
 @pytest.mark.gpu

@@ -296,6 +296,45 @@ def test_netcdf4_writer_parallel_chunks_round_trip(tmp_path, monkeypatch):
     assert "CHUNKED" == hdr["y_pos"]["layout"] and "DEFLATE { LEVEL 2 }" in hdr["y_pos"]["filters"] and "SHUFFLE" in hdr["mask"]["filters"]
 
 
+def test_netcdf4_writer_failure_closes_and_removes_the_partial_file(tmp_path, monkeypatch):
+    """A failure while the queued chunks are handed to libhdf5 (or while the scales are attached): every id is closed, the
+    half-written file is removed, the ORIGINAL error is what the caller sees, and the bounded queue flushes early."""
+    from sitrack_amd import h5lite
+    if not h5lite.writer_available():
+        pytest.skip("libhdf5 / libhdf5_hl not loadable here")
+    monkeypatch.setattr(ncio, "_nc4", None)
+    monkeypatch.setenv("SITRK_NC_COMPLEVEL", "1")
+    Nb = (1 << 20) + 7
+    ids = np.arange(Nb, dtype=np.int64)
+    Y = np.zeros((2, Nb)); X = np.ones((2, Nb))
+    f = str(tmp_path / "NEMO-SI3_A_B_tracking12_fail.nc")
+    real_flush = h5lite.NC4Writer.flush
+    calls = []
+
+    def bad_flush(self):
+        calls.append(len(getattr(self, "_pending", [])))
+        real_flush(self)
+        raise OSError("disk full (injected)")
+    monkeypatch.setattr(h5lite.NC4Writer, "flush", bad_flush)
+    with pytest.raises(OSError, match="disk full"):
+        ncio.ncSaveCloudBuoys(f, np.array([10, 20]), ids, Y, X, Y, X)
+    assert not os.path.exists(f) and calls and calls[0] > 0
+    # the same writer class then writes a good file (no id leaked that would keep the name busy)
+    monkeypatch.setattr(h5lite.NC4Writer, "flush", real_flush)
+    monkeypatch.setenv("SITRK_NC_PENDING_BYTES", str(5 << 20))          # every large variable flushes by itself
+    nfl = []
+    monkeypatch.setattr(h5lite.NC4Writer, "flush", lambda self: (nfl.append(1), real_flush(self))[1])
+    ncio.ncSaveCloudBuoys(f, np.array([10, 20]), ids, Y, X, Y, X)
+    assert len(nfl) >= 4
+    tt, bid, ll, yx = ncio.LoadNCdata(f, krec=-1)[:4]
+    assert np.array_equal(bid, ids) and np.all(yx[..., 1] == 1.0)
+    # an error raised by the caller's own data before close(): abort() path
+    w = h5lite.NC4Writer(f)
+    w.createDimension('time', None)
+    w.abort(); w.abort()
+    assert not os.path.exists(f) and w.fid == -1
+
+
 def _write_nc3(fname, dims, variables, attrs=None):
     from scipy.io import netcdf_file
     f = netcdf_file(fname, 'w', version=2)

@@ -517,9 +517,21 @@ def test_async_ingest_ring_and_staging():
                 ctx.push_record(s % K, tu, tv, ts)
                 tu[:] = np.nan; tv[:] = 1e30; ts[:] = 0.
             elif s % 3 == 1:                                # straight into the library's pinned staging
-                bu, bv, bs = ctx.stage()
-                bu[...] = u[s]; bv[...] = v[s]; bs[...] = sic[s]
-                ctx.submit(s % K)
+                if s % 2:
+                    bu, bv, bs = ctx.stage()
+                    bu[...] = u[s]; bv[...] = v[s]; bs[...] = sic[s]
+                    ctx.submit(s % K)
+                else:
+                    # a reader that fails half-way must leave the context usable (sitrk_stage_release), then the real read
+                    def bad(bu, bv, bs):
+                        bu[...] = np.nan
+                        raise IOError("file vanished")
+                    with pytest.raises(IOError):
+                        ctx.stage_fill(s % K, 0, Nj, bad)
+
+                    def good(bu, bv, bs):
+                        bu[...] = u[s]; bv[...] = v[s]; bs[...] = sic[s]
+                    ctx.stage_fill(s % K, 0, Nj, good)
             else:                                           # as a row band that happens to be the whole record
                 ctx.push_record_rows(s % K, 0, Nj, u[s], v[s], sic[s])
         m = K // 2
