@@ -240,6 +240,78 @@ def g5_seedinit():
          nPn=np.int64(nPn), oSG=oSG, oSC=oSC, oIDs=oIDs, ojiT=np.asarray(ojiT), overt=np.asarray(overt), okeep=okeep)
 
 
+# --------------------------------------------------------------------------- G5b
+def g5b_seedinit_on_points():
+    """Seeds EXACTLY on T- and F-points of a curvilinear polar mesh, as the reference's own seeding emits them
+    (`tracking.nemoSeed(..., platF, plonF)`, tracking.py:365-442: the grid's lat/lon values themselves), through the
+    reference's `SeedInit` / `NearestPoint`.  An F-point is (nearly) equidistant from four T-points: the argmin is decided
+    by the last bits of the Haversine distances, `Survive` is evaluated on whichever T-point wins and
+    `FindContainingCell` only tries that point's five candidate cells, so kept/cancelled depends on the tie.
+    Two meshes (warped: near ties; regular: rounding-level ties) x two seed precisions: as the seeding file stores them
+    (float32 promoted to float64, lon mod 360, ncio.py:294-309) and at full precision.
+    The seeds' plane coordinates come from the build's forward projection (inputs only: cartopy is absent)."""
+    from oracle import oracle as orc
+    out = {}
+    for tag, warp, (yc, xc) in (("w", 1.0, (-300., 200.)), ("r", 0.0, (-700., -450.)), ("l", None, (0., 0.))):
+        Nj, Ni, dkm = 30, 34, 12.0
+        if warp is not None:
+            g = polar_grid(Nj, Ni, dkm, warp=warp, yc=yc, xc=xc)
+            llF = orc.CartNPSkm2Geo1D(np.stack([g["Yf"].ravel(), g["Xf"].ravel()], axis=1))
+            latF = np.ascontiguousarray(llF[:, 0].reshape(Nj, Ni))
+            lonF = np.ascontiguousarray(np.mod(llF[:, 1], 360.).reshape(Nj, Ni))
+        else:
+            # a mesh that is REGULAR IN LATITUDE / LONGITUDE with dyadic steps: an F-point sits exactly half a step east of
+            # T[j,i] and T[j,i+1] at a common latitude, so the two Haversine distances are EQUAL to the last bit and the
+            # reference's argmin (first minimum in C order, locate.py:13-20) decides -- exact two-way ties
+            jj, ii = np.meshgrid(np.arange(Nj), np.arange(Ni), indexing="ij")
+            latT = 72. + 0.125 * jj; lonT = 10. + 0.5 * ii
+            latF = latT + 0.0625; lonF = lonT + 0.25
+            def plane(la, lo):
+                yx_ = orc.Geo2CartNPSkm1D(np.stack([la.ravel(), lo.ravel()], axis=1))
+                return np.ascontiguousarray(yx_[:, 0].reshape(Nj, Ni)), np.ascontiguousarray(yx_[:, 1].reshape(Nj, Ni))
+            Yf, Xf = plane(latF, lonF)
+            tm = np.ones((Nj, Ni), dtype="i1"); tm[:2] = 0; tm[-2:] = 0; tm[:, :2] = 0; tm[:, -2:] = 0
+            g = {"latT": latT, "lonT": lonT, "Yf": Yf, "Xf": Xf, "resol": np.full((Nj, Ni), 19.0), "tmask": tm}
+        tmask = g["tmask"].copy()
+        tmask[12:15, 8:11] = 0
+        sic = np.ones((Nj, Ni)); sic[4:9, 20:28] = 0.02; sic[18:22, 5:9] = 0.93; sic[20, 14] = 0.1
+        with quiet():
+            seeds = tracking.nemoSeed(tmask, g["latT"], g["lonT"], sic, khss=1, platF=latF, plonF=lonF)
+        nP = seeds.shape[0]
+        yx = orc.Geo2CartNPSkm1D(seeds)
+        ids = (np.arange(nP) + 1).astype(np.int64) * 3
+        out.update({tag + "_latT": g["latT"], tag + "_lonT": g["lonT"], tag + "_Yf": g["Yf"], tag + "_Xf": g["Xf"],
+                    tag + "_resol": g["resol"], tag + "_tmask": tmask, tag + "_sic": sic, tag + "_latF": latF, tag + "_lonF": lonF,
+                    tag + "_ids": ids})
+        for prec in ("f4", "f8"):
+            if prec == "f4":
+                pSG = np.stack([seeds[:, 0].astype(np.float32).astype(np.float64),
+                                np.mod(seeds[:, 1].astype(np.float32).astype(np.float64), 360.)], axis=1)
+                pSC = yx.astype(np.float32).astype(np.float64)
+            else:
+                pSG = np.stack([seeds[:, 0], np.mod(seeds[:, 1], 360.)], axis=1)
+                pSC = yx.copy()
+            npj = np.empty((nP, 2), dtype=np.int64)
+            dmin = np.empty(nP); gap = np.empty(nP)
+            with quiet():
+                for k in range(nP):
+                    npj[k] = locate.NearestPoint((pSG[k, 0], pSG[k, 1]), g["latT"], g["lonT"], rd_found_km=tracking.rFoundKM,
+                                                 resolkm=g["resol"], max_itr=10)
+                    xd = np.sort(util.Haversine(pSG[k, 0], pSG[k, 1], g["latT"], g["lonT"]).ravel())
+                    dmin[k] = xd[0]; gap[k] = xd[1] - xd[0]
+                res = tracking.SeedInit(ids.copy(), pSG.copy(), pSC.copy(), g["latT"], g["lonT"], g["Yf"], g["Xf"],
+                                        g["resol"], tmask, xIceConc=sic, iverbose=0)
+            nPn, oSG, oSC, oIDs, ojiT, overt, okeep = res
+            k0 = tag + "_" + prec + "_"
+            out.update({k0 + "pSG": pSG, k0 + "pSC": pSC, k0 + "nearest": npj, k0 + "dmin": dmin, k0 + "gap": gap,
+                        k0 + "nPn": np.int64(nPn), k0 + "oSG": oSG, k0 + "oSC": oSC, k0 + "oIDs": oIDs,
+                        k0 + "ojiT": np.asarray(ojiT), k0 + "overt": np.asarray(overt), k0 + "okeep": okeep})
+            ntie = int((gap < 1e-9).sum())
+            print("   G5b %s/%s: %d seeds (T then F) -> %d kept; %d with the two smallest distances within 1e-9 km, %d exactly equal"
+                  % (tag, prec, nP, nPn, ntie, int((gap == 0).sum())))
+    save("g5b_seeds_on_points.npz", **out)
+
+
 # --------------------------------------------------------------------------- G6
 def reference_loop(g, tmask, u, v, sic, yx0, jiT0, vert0, rec_first, rec_last, kstrt, Nt, rdt, strategy):
     """Drives the reference predicates in the order of si3_part_tracker.py:361-496.
@@ -425,7 +497,7 @@ def g10_nemoseed():
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, fn in (("g1", g1_inside), ("g2", g2_intersect), ("g3", g3_crossing), ("g4", g4_survive),
-                     ("g5", g5_seedinit), ("g6", g6_trajectories), ("g7", g7_projection), ("g8", g8_timespan),
+                     ("g5", g5_seedinit), ("g5b", g5b_seedinit_on_points), ("g6", g6_trajectories), ("g7", g7_projection), ("g8", g8_timespan),
                      ("g9", g9_haversine), ("g10", g10_nemoseed)):
         if not only or name in only:
             fn()

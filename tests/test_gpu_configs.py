@@ -111,22 +111,22 @@ def test_c4_rank_shards_and_partition_invariance(c4):
         assert np.array_equal(both[k], np.concatenate([outs[0][k], outs[1][k]])), k
 
 
-def test_c5_shape_cli_on_a_nanuk4_shaped_mesh(tmp_path, monkeypatch):
-    """NANUK4-SHAPED, not NANUK4: synthetic 566 x 492 mesh at 12.5 km, hourly records, >= 1e6 seeds under a synthetic ice
-    mask (a seed is kept where `nemoSeed` would seed its nearest T-point: tmask = 1, lat >= 55, siconc >= 0.9), the
-    reference's default 2-D-time mode with late starters / early stoppers.  The command line runs files in -> files
-    out; every 997th kept buoy is replayed on the oracle from the seed cache the run wrote."""
+def _c5_cli_case(tmp_path, monkeypatch, ncand, nrec, min_seeds, stride):
+    """The command line, files in -> files out, on the NANUK4-shaped synthetic mesh with `ncand` candidate seeds filtered by
+    `nemoSeed`'s rule; every `stride`-th kept buoy is replayed on the oracle from the seed cache the run wrote."""
+    import time
     import test_driver as td
     from oracle import oracle as orc
     from sitrack_amd import driver as drv, ncio
     monkeypatch.chdir(tmp_path)
-    nrec = 40
-    c = td.make_case(str(tmp_path), nrec=nrec, nP=1_300_000, Nj=566, Ni=492, dkm=12.5, two_d_time=True, ice_mask_seeding=True)
-    assert len(c["ids"]) >= 1_000_000
+    c = td.make_case(str(tmp_path), nrec=nrec, nP=ncand, Nj=566, Ni=492, dkm=12.5, two_d_time=True, ice_mask_seeding=True)
+    assert len(c["ids"]) >= min_seeds
+    t0 = time.perf_counter()
     out = drv.main(["-i", c["si3"], "-m", c["mm"], "-s", c["seed"], "-N", "TEST4"])
+    wall = time.perf_counter() - t0
     with np.load(glob.glob("./seed/Initialized_buoys_*.npz")[0]) as z:
         nP, xPosC0, vJIt0, keep = int(z["nP"]), z["xPosC0"], z["vJIt"], z["idxKeep"]
-    assert nP == out["nP"] and nP > 900_000
+    assert nP == out["nP"] and nP > 0.9 * min_seeds
     imaskt, _, _, _, _, xYf, xXf, _ = ncio.GetModelGrid(c["mm"])
     xYv, xXv, xYu, xXu = ncio.GetModelUVGrid(c["mm"])
     grid = dict(Yf=xYf, Xf=xXf, Yu=xYu, Xu=xXu, Yv=xYv, Xv=xXv, tmask=imaskt)
@@ -135,7 +135,7 @@ def test_c5_shape_cli_on_a_nanuk4_shaped_mesh(tmp_path, monkeypatch):
     tp1 = np.full(n0, tc[-1] + 1800); tp1[::5] = base + 9 * 3600
     z1, zL = drv.record_windows(np.stack([tp0, tp1]), tc, 0, len(tc) - 1, tc[0], tc[-1], n0)
     z1, zL = z1[keep], zL[keep]
-    sub = np.arange(0, nP, 997)
+    sub = np.arange(0, nP, stride)
     ref = orc.Tracker(grid, xPosC0[sub], vJIt0[sub], rec_first=z1[sub], rec_last=zL[sub], nthreads=8)
     last = xPosC0[sub].copy()
     for jt in range(len(tc)):
@@ -148,3 +148,22 @@ def test_c5_shape_cli_on_a_nanuk4_shaped_mesh(tmp_path, monkeypatch):
     ok = mk2[1][sub] == 1
     assert ok.sum() > 0.5 * len(sub)
     assert np.array_equal(yx2[1][sub][ok].astype('f4'), last[ok].astype('f4'))
+    return out, wall, nP
+
+
+def test_c5_shape_cli_on_a_nanuk4_shaped_mesh(tmp_path, monkeypatch):
+    """NANUK4-SHAPED, not NANUK4: synthetic 566 x 492 mesh at 12.5 km, hourly records, >= 1e6 seeds under a synthetic ice
+    mask (a seed is kept where `nemoSeed` would seed its nearest T-point: tmask = 1, lat >= 55, siconc >= 0.9), the
+    reference's default 2-D-time mode with late starters / early stoppers.  The command line runs files in -> files
+    out; every 997th kept buoy is replayed on the oracle from the seed cache the run wrote."""
+    _c5_cli_case(tmp_path, monkeypatch, 1_300_000, 40, 1_000_000, 997)
+
+
+def test_c5_size_cli_1e7_seeds_under_the_ice_mask(tmp_path, monkeypatch):
+    """BASELINE config 5 at its SIZE (the mesh is still the NANUK4-shaped synthetic one): >= 1e7 seeds under the ice mask,
+    48 hourly records, 2-D-time mode, files in -> files out through the command line (4 fused launches of the windowed
+    kernel form, NetCDF-4 output at deflate 9), every 3989th kept buoy replayed on the oracle.  (tests/sweeps/demo_cli.py
+    --big, 7.2 s in profiles/r02aq_cli_demo_1e7.json, promoted into the GPU suite.)"""
+    out, wall, nP = _c5_cli_case(tmp_path, monkeypatch, 11_300_000, 48, 10_000_000, 3989)
+    assert out["launches"]["fused_launches"] >= 2 and out["launches"]["step_launches"] <= 2
+    print("C5 size: %d buoys kept of %d seeds, command line %.1f s, launches %s" % (nP, len(out["IDs"]), wall, out["launches"]))

@@ -683,6 +683,33 @@ def test_seed_init_bruteforce_mode_matches_golden(golden, ctx):
     assert out[0] == int(g["nPn"]) and np.array_equal(out[6], g["okeep"]) and np.array_equal(out[4], g["ojiT"])
 
 
+@pytest.mark.parametrize("bruteforce", [0, 1])
+@pytest.mark.parametrize("prec", ["f4", "f8"])
+@pytest.mark.parametrize("mesh", ["w", "r", "l"])
+def test_seed_init_on_t_and_f_points_matches_reference_golden(golden, ctx, mesh, prec, bruteforce):
+    """G5b through `sitrk_seed_init`, both locate modes, bit for bit: seeds exactly on T- and F-points as the reference's
+    `nemoSeed(..., platF, plonF)` emits them (tracking.py:426-440).  Mesh "l" holds 581 seeds whose two nearest T-points
+    are at EXACTLY equal Haversine distance in numpy: the device's libm must produce the tie as well and break it toward
+    the lowest flat index (locate.py:13-20); on meshes "w"/"r" the nearest gaps go down to 1e-6 km."""
+    g = golden("g5b_seeds_on_points.npz")
+    G = lambda k: g[mesh + "_" + k]                                       # noqa: E731
+    P = lambda k: g[mesh + "_" + prec + "_" + k]                          # noqa: E731
+    ctx.set_grid(G("Yf"), G("Xf"), G("Yf"), G("Xf"), G("Yf"), G("Xf"), G("tmask"))
+    ctx.set_tuning(locate_bruteforce=bruteforce)
+    try:
+        out = sit.SeedInit(G("ids"), P("pSG"), P("pSC"), G("latT"), G("lonT"), G("Yf"), G("Xf"), G("resol"), G("tmask"),
+                           xIceConc=G("sic"), ctx=ctx)
+        near, dmin = ctx.nearest_point(P("pSG"), G("latT"), G("lonT"), resolkm=G("resol"), rd_found_km=2.5, max_itr=10)
+    finally:
+        ctx.set_tuning(locate_bruteforce=0)
+    nPn, oSG, oSC, oIDs, ojiT, overt, okeep = out
+    assert nPn == int(P("nPn")) and np.array_equal(okeep, P("okeep")) and np.array_equal(oIDs, P("oIDs"))
+    assert np.array_equal(ojiT, P("ojiT")) and np.array_equal(overt, P("overt"))
+    assert np.array_equal(oSG, P("oSG")) and np.array_equal(oSC, P("oSC"))
+    assert np.array_equal(near, P("nearest"))
+    assert np.allclose(dmin, P("dmin"), rtol=1e-12, atol=1e-9)
+
+
 @pytest.mark.parametrize("yc,xc", [(-300., 200.), (0., 0.), (-2500., 1800.)])
 def test_seed_search_equals_whole_grid_scan(ctx, yc, xc):
     """Bounding-sphere search == exhaustive Haversine argmin, incl. seeds exactly on T- and F-points

@@ -118,6 +118,28 @@ def test_g5_seedinit(golden):
     assert np.array_equal(oSG, g["oSG"]) and np.array_equal(oSC, g["oSC"])
 
 
+@pytest.mark.parametrize("prec", ["f4", "f8"])
+@pytest.mark.parametrize("mesh", ["w", "r", "l"])
+def test_g5b_seeds_exactly_on_t_and_f_points(golden, mesh, prec):
+    """G5b: the reference's SeedInit / NearestPoint on seeds that sit exactly on T- and F-points as `nemoSeed(..., platF,
+    plonF)` emits them -- near ties (warped and regular polar meshes) and EXACT two-way ties (a mesh regular in lat/lon:
+    the first minimum in C order wins, locate.py:13-20), at the seeding file's float32 and at full precision."""
+    g = golden("g5b_seeds_on_points.npz")
+    G = lambda k: g[mesh + "_" + k]                                       # noqa: E731
+    P = lambda k: g[mesh + "_" + prec + "_" + k]                          # noqa: E731
+    nP = len(G("ids"))
+    for k in range(0, nP, 3):
+        jy, jx = orc.NearestPoint(P("pSG")[k], G("latT"), G("lonT"), rd_found_km=orc.rFoundKM, resolkm=G("resol"), max_itr=10)
+        assert (jy, jx) == tuple(P("nearest")[k]), k
+    nPn, oSG, oSC, oIDs, ojiT, overt, okeep = orc.SeedInit(G("ids"), P("pSG"), P("pSC"), G("latT"), G("lonT"), G("Yf"), G("Xf"),
+                                                           G("resol"), G("tmask"), G("sic"))
+    assert nPn == int(P("nPn")) and np.array_equal(okeep, P("okeep")) and np.array_equal(oIDs, P("oIDs"))
+    assert np.array_equal(ojiT, P("ojiT")) and np.array_equal(overt, P("overt"))
+    assert np.array_equal(oSG, P("oSG")) and np.array_equal(oSC, P("oSC"))
+    if mesh == "l":
+        assert (P("gap") == 0).sum() > 500                                # the exact ties are really in the set
+
+
 @pytest.mark.parametrize("tag", ["curvi", "regular"])
 @pytest.mark.parametrize("strat", [1, 0])
 def test_g6_trajectories_bit_exact(golden, tag, strat):

@@ -7,8 +7,8 @@ for r in 1 2; do
   n=0
   for t in "${SETS[@]}"; do
     n=$((n+1))
-    python bench.py $ARGS ${t:+--tune $t} > gpurun_out/${TAG}_$n_$r.json 2> gpurun_out/${TAG}_$n_$r.err || { echo "[$t] failed"; tail -3 gpurun_out/${TAG}_$n_$r.err; }
-    python - "$t" gpurun_out/${TAG}_$n_$r.json <<'PY'
+    python bench.py $ARGS ${t:+--tune $t} > gpurun_out/${TAG}_${n}_${r}.json 2> gpurun_out/${TAG}_${n}_${r}.err || { echo "[$t] failed"; tail -3 gpurun_out/${TAG}_${n}_${r}.err; }
+    python - "$t" gpurun_out/${TAG}_${n}_${r}.json <<'PY'
 import json, sys
 try:
     d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
