@@ -189,6 +189,18 @@ def parse():
     return ap.parse_args()
 
 
+# The reference's OWN Python loop cannot run on the GPU box (no /root/reference there): it was timed in the build container
+# by tools/time_reference_loop.py -- the imported reference functions in the loop order of si3_part_tracker.py:378-490, 10^3
+# buoys x 100 records cut from the C2 / C3 inputs, one core -- and travels as constants with their provenance
+# (profiles/r03b_reference_python_loop.json).
+REFERENCE_PYTHON = {
+    "c2": 40867.0, "c3": 10692.1, "c3_without_the_per_record_grid_assignments": 24476.0,
+    "unit": "particle-steps/s", "cores": 1, "cpu": 'Intel(R) Xeon(R) Processor @ 2.10GHz', "date": '2026-10-05',
+    "sample": "first 1000 buoys x 100 records of the C2 / C3 inputs, iUVstrategy = 1",
+    "source": "tools/time_reference_loop.py -> profiles/r03b_reference_python_loop.json (build container; the GPU box has no reference)",
+}
+
+
 def cpu_baseline(grid, u, v, sic, yx, ji, target_s, uv_strategy):
     """Oracle on host cores: bounded sample of the same workload (first nS buoys x a few records)."""
     from oracle import oracle as orc
@@ -216,7 +228,8 @@ def cpu_baseline(grid, u, v, sic, yx, ji, target_s, uv_strategy):
     rate, nS, nrec = out[cores]
     return {"value": rate, "unit": "particle-steps/s", "cores": cores, "kind": "port",
             "sample": "first %d buoys x %d records of the same workload, fp64 oracle with OpenMP over buoys" % (nS, nrec),
-            "value_1core": out[1][0], "sample_1core": "%d buoys x %d records" % (out[1][1], out[1][2])}
+            "value_1core": out[1][0], "sample_1core": "%d buoys x %d records" % (out[1][1], out[1][2]),
+            "reference_python": REFERENCE_PYTHON}
 
 
 def cpu_baseline_check(ctx, grid, u, v, sic, yx, ji, nsteps, uv_strategy, nS=20000):
@@ -720,24 +733,42 @@ def main():
 
         def roofline_fused(ev_ms_total, st):
             """advect_run_kernel: state and geometry are read once per launch, so it is bound by fp64 VALU issue, not by
-            HBM.  frac = VALU instructions issued per second / what 1024 SIMDs can issue at the 2.4 GHz peak clock, with
-            the instructions per wave per record taken from the committed rocprofv3 counters (SQ_INSTS_VALU / SQ_WAVES /
-            records per launch) and the launches and records counted by the library in THIS run."""
+            HBM.  achieved = VALU instructions issued per second: (fixed per launch + per record x records) per wave, both
+            terms fitted from committed rocprofv3 counters of launches of different lengths (tools/fit_valu_terms.py ->
+            profiles/traffic.json), for the launches and records COUNTED BY THE LIBRARY in this run.  The ceiling weights
+            the instruction mix: a wave64 instruction of the 64-bit classes holds its SIMD 4 cycles, a 32-bit one 2
+            (share of the 64-bit classes from the per-class counters of the same profile; static ISA count: 0.83,
+            tools/isa_valu_classes.py).  frac is quoted against the 2.4 GHz maximum clock and against the clock the chip
+            held under this kernel in the profiled run."""
             nl, nr, ns = st["fused_launches"], st["fused_records"], st["step_launches"]
-            ipwr = prof_fused.get("valu_per_wave_record")
             rpl = nr / nl if nl else 0.0
+            fixed, per = prof_fused.get("valu_per_wave_fixed"), prof_fused.get("valu_per_wave_per_record")
+            if fixed is not None and per is not None and rpl:
+                ipwr = (fixed + per * rpl) / rpl                      # for THIS run's launch length
+                ipwr_src = "%.1f fixed per launch + %.2f per record, %s" % (fixed, per, prof_fused.get("valu_terms_source"))
+            else:
+                ipwr = prof_fused.get("valu_per_wave_record")         # one launch length only (older profiles)
+                ipwr_src = prof_fused.get("source")
             # the timed region = nl fused launches (+ ns one-record launches where a re-sort or the tail cut a launch short)
             launch_ms = ev_ms_total / max(nl + ns, 1)
             rec_s = (ev_ms_total / 1e3) / max(nr + ns, 1)
             A = 50.0 * nP + 48.0 * n_cells + 8.0 * n_cells * rpl          # bytes one launch of rpl records needs
-            out = {"bound": "fp64_valu_issue", "unit": "Ginst/s", "peak": VALU_PEAK_GINST,
+            w64 = prof_fused.get("valu64_frac")
+            cpi = 4.0 * w64 + 2.0 * (1.0 - w64) if w64 is not None else 4.0
+            peak = 1024 * 2.4 / cpi
+            held = prof_fused.get("sclk_ghz")
+            out = {"bound": "fp64_valu_issue", "unit": "Ginst/s", "peak": peak,
                    "kernel": "advect_run_kernel", "launches": nl, "records_advanced": nr, "one_record_launches": ns,
                    "records_per_launch": rpl, "avg_launch_ms": launch_ms, "waves_per_launch": nwaves,
-                   "valu_inst_per_wave_record": ipwr, "valu_inst_source": prof_fused.get("source"),
-                   "peak_note": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction"}
+                   "valu_inst_per_wave_record": ipwr, "valu_inst_source": ipwr_src,
+                   "valu64_class_share": w64, "cycles_per_valu_inst": cpi,
+                   "peak_note": "1024 SIMDs x 2.4 GHz / (4 cycles x share of 64-bit-class VALU instructions + 2 cycles x the rest)",
+                   "peak_uniform_4_cycles": VALU_PEAK_GINST}
             if ipwr:
                 ach = ipwr * nwaves / rec_s / 1e9
-                out.update({"achieved": ach, "frac": ach / VALU_PEAK_GINST})
+                out.update({"achieved": ach, "frac": ach / peak, "frac_uniform_4_cycles": ach / VALU_PEAK_GINST,
+                            "clock_held_ghz": held, "clock_held_source": prof_fused.get("source"),
+                            "frac_at_held_clock": (ach / (1024 * held / cpi)) if held else None})
             else:
                 out.update({"achieved": None, "frac": None})
             tr = prof_fused.get("hbm_bytes_per_launch") if a.buoys == 0 else None
@@ -745,10 +776,16 @@ def main():
             out["traffic"] = tr * rpl / tr_rpl if (tr and rpl) else None
             out["traffic_note"] = ("rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE of a %d-record launch (%s), scaled to %.1f records"
                                    % (tr_rpl, prof_fused.get("source"), rpl)) if tr else None
-            out["hbm"] = {"algorithmic_bytes_per_launch": A, "achieved": A / (launch_ms / 1e3) / 1e9 if nl else None,
-                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": A / (launch_ms / 1e3) / 1e9 / HBM_PEAK_GBS if nl else None,
+            s_launch = launch_ms / 1e3
+            out["hbm"] = {"algorithmic_bytes_per_launch": A, "achieved": A / s_launch / 1e9 if nl else None,
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": A / s_launch / 1e9 / HBM_PEAK_GBS if nl else None,
                           "cells_needed": n_cells,
-                          "note": "secondary: the fused kernel is not HBM bound; per_record_launch holds the HBM-bound form"}
+                          "survey_formula_bytes_per_launch": A_survey * rpl,
+                          "survey_formula_frac": A_survey * rpl / s_launch / 1e9 / HBM_PEAK_GBS if nl else None,
+                          "note": "secondary: the fused kernel is not HBM bound; per_record_launch holds the HBM-bound form.  "
+                                  "survey_formula_frac charges SURVEY 8d's per-step bytes (50 B per buoy + 56 B for EVERY cell of the "
+                                  "grid) to every record of the launch and comes out ABOVE 1: the launch reads state and geometry once "
+                                  "for all its records (loop interchange), and only the cells that host buoys (cells_needed) are read"}
             return out
 
         if a.regime == "resident" and fuse > 1 and stats["fused_launches"] > 0:

@@ -90,6 +90,17 @@ def main():
             res["valu_busy_frac"] = a["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / cyc
             if "SQ_INSTS_VALU" in a and "SQ_WAVES" in a:
                 res["valu_insts_per_wave"] = a["SQ_INSTS_VALU"] / a["SQ_WAVES"]
+                if "SQ_INSTS_SALU" in a:
+                    res["salu_insts_per_wave"] = a["SQ_INSTS_SALU"] / a["SQ_WAVES"]
+                # instruction classes (their own PMC pass): 64-bit classes occupy the SIMD 4 cycles per wave64 instruction, 32-bit ones 2
+                c64 = [a.get("SQ_INSTS_VALU_%s" % k) for k in ("ADD_F64", "MUL_F64", "FMA_F64", "TRANS_F64", "INT64")]
+                if all(v is not None for v in c64):
+                    res["valu_class_counts_per_wave"] = {k: a.get("SQ_INSTS_VALU_%s" % k, 0.0) / a["SQ_WAVES"]
+                                                         for k in ("ADD_F64", "MUL_F64", "FMA_F64", "TRANS_F64", "INT64", "CVT", "INT32", "ADD_F32")}
+                    res["valu64_frac_counters"] = sum(c64) / a["SQ_INSTS_VALU"]
+                    lines.append("Instruction classes: ADD/MUL/FMA/TRANS_F64 + INT64 = %.1f %% of SQ_INSTS_VALU (CVT %.1f %%, INT32 %.1f %%)."
+                                 % (100 * res["valu64_frac_counters"], 100 * a.get("SQ_INSTS_VALU_CVT", 0) / a["SQ_INSTS_VALU"],
+                                    100 * a.get("SQ_INSTS_VALU_INT32", 0) / a["SQ_INSTS_VALU"]))
                 if fused:
                     res["records_per_launch"] = rec_per_launch
                     res["valu_per_wave_record"] = res["valu_insts_per_wave"] / rec_per_launch
@@ -122,6 +133,11 @@ def main():
                                                         "valu_busy_frac": res.get("valu_busy_frac"), "sclk_ghz": res.get("sclk_ghz"),
                                                         "valu_per_wave_record": res.get("valu_per_wave_record"),
                                                         "records_per_launch": res.get("records_per_launch")}
+        prev = (json.load(open(tj)) if os.path.exists(tj) else {}).get(config + "_fused" if fused else config, {})
+        for k in ("valu_per_wave_fixed", "valu_per_wave_per_record", "valu_terms_source", "valu64_frac", "valu64_frac_source",
+                  "salu_per_wave_fixed", "salu_per_wave_per_record"):
+            if k in prev:                         # fitted by tools/fit_valu_terms.py from several launch lengths: keep
+                allt[config + "_fused" if fused else config][k] = prev[k]
         json.dump(allt, open(tj, "w"), indent=1)
     print("\n".join(lines))
 
