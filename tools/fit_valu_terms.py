@@ -18,7 +18,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
-    config, files = sys.argv[1], sys.argv[2:]
+    argv = list(sys.argv[1:])
+    isa = None
+    if "--isa" in argv:                      # tools/isa_valu_classes.py --json: the hot-block share of 64-bit-class instructions
+        k = argv.index("--isa")
+        isa = json.load(open(argv[k + 1]))
+        isa_name = os.path.basename(argv[k + 1])
+        del argv[k:k + 2]
+    config, files = argv[0], argv[1:]
     pts = [json.load(open(f)) for f in files]
     n = np.array([p["records_per_launch"] for p in pts], dtype=float)
     out = {}
@@ -32,8 +39,16 @@ def main():
         print("%s per wave = %.1f + %.2f x records   (points: %s)" % (name.upper(), fixed, per, ", ".join("%d: %.1f" % (a, b) for a, b in zip(n, y))))
     w = [p["valu64_frac_counters"] for p in pts if "valu64_frac_counters" in p]
     if w:
+        # the per-class counters see fp64 arithmetic and 64-bit integer ops only -- not fp64 compares, conversions, 64-bit moves:
+        # a LOWER bound of the share of instructions that hold the SIMD 4 cycles
+        out["valu64_frac_counters_lower_bound"] = float(np.mean(w))
         out["valu64_frac"] = float(np.mean(w))
         out["valu64_frac_source"] = "SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 + _INT64 over SQ_INSTS_VALU, " + ", ".join(os.path.basename(f) for f in files)
+    if isa is not None:
+        out["valu64_frac"] = float(isa["hot_blocks"]["valu64_frac"])
+        out["valu64_frac_source"] = ("ISA listing, blocks a wave executes per record (tools/isa_valu_classes.py -> %s): %.0f of %.0f VALU "
+                                     "instructions are of the 64-bit classes (fp64 arithmetic, compares, conversions, 64-bit integer/moves)"
+                                     % (isa_name, isa["hot_blocks"]["valu64"], isa["hot_blocks"]["valu"]))
     out["valu_terms_source"] = ", ".join(os.path.basename(f) for f in files)
     tj = os.path.join(ROOT, "profiles", "traffic.json")
     allt = json.load(open(tj))

@@ -66,9 +66,53 @@ def main():
             cls["lds"] += 1
         else:
             cls["other"] += 1
+    # ---- the blocks a C3 wave really executes per record ("hot"): everything but the fall-backs -- exact divisions
+    # (v_div_*/v_rcp_f64), the plain IsInsideQuadrangle (v_min/max_f64), the crossing path through global memory (a block
+    # that reads the crossing table from LDS AND loads points with global_load_dwordx4: lanes outside the patch) -- with the
+    # four per-edge regions of the filtered cell test (the blocks with v_cmp_lt_i64 on the cross product) counted at 1/2:
+    # a buoy's +x ray is level with the cell's right edge and, in warped cells, one more
+    blocks, cur = [], None
+    for i in range(hdr, len(body)):
+        l = body[i]
+        if l.startswith(".LBB") or l.startswith("; %bb."):
+            if l.startswith(".LBB") and i > hdr and tag not in l and not any(tag in b for b in body[i:]):
+                break
+            cur = {"v64": 0, "v32": 0, "cold": False, "edge": False, "tab": False, "gld4": False}
+            blocks.append(cur)
+            continue
+        t = l.strip()
+        if cur is None or not t or t.startswith(";") or t.startswith("."):
+            continue
+        mn = t.split()[0]
+        if mn.startswith("v_"):
+            cur["v64" if is64(mn) else "v32"] += 1
+            if mn.startswith(("v_div_", "v_rcp_f64", "v_min_f64", "v_max_f64")):
+                cur["cold"] = True
+            if mn.startswith("v_cmp_lt_i64"):
+                cur["edge"] = True
+        elif mn.startswith("ds_read_b128"):
+            cur["tab"] = True
+        elif mn.startswith("global_load_dwordx4"):
+            cur["gld4"] = True
+    h64 = h32 = 0.0
+    skip = 0
+    for b in blocks:
+        if b["tab"] and b["gld4"] and b["v64"] > 20:
+            skip = 2                                             # the global-memory crossing block and its lazy second half
+            continue
+        if skip and b["v64"] in (12, 0):
+            skip -= 1
+            continue
+        skip = 0
+        if b["cold"]:
+            continue
+        w = 0.5 if b["edge"] else 1.0
+        h64 += w * b["v64"]; h32 += w * b["v32"]
     nv = cls["valu64"] + cls["valu32"]
     res = {"kernel": key, "loop_header": name, "static": cls, "valu": nv, "valu64_frac_static": cls["valu64"] / max(nv, 1),
            "cycles_per_valu_static": (4.0 * cls["valu64"] + 2.0 * cls["valu32"]) / max(nv, 1),
+           "hot_blocks": {"valu64": h64, "valu32": h32, "valu": h64 + h32, "valu64_frac": h64 / max(h64 + h32, 1e-9),
+                          "cycles_per_valu": (4.0 * h64 + 2.0 * h32) / max(h64 + h32, 1e-9)},
            "note": "static counts over every block of the loop (all paths, cold division blocks included); the dynamic mix comes from the PMC class counters"}
     print(json.dumps(res, indent=1))
     if "--json" in sys.argv:

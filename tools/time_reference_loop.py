@@ -46,7 +46,7 @@ def main():
     a = ap.parse_args()
     import gen_golden as gg                                  # imports the reference (refload) at module scope
     from sitrack_amd import synthetic as syn
-    from oracle import oracle as orc
+    from sitrack_amd.tracking import vertices_of          # VRTCS from vJIt (locate.py:320-321); no GPU needed
     shapes = {"c2": (512, 512, 100_000), "c3": (4096, 4096, 10_000_000)}
     out = {"cpu": cpu_model(), "cores_used": 1, "python": platform.python_version(), "numpy": np.__version__,
            "date": time.strftime("%Y-%m-%d"), "buoys": a.buoys, "records": a.records,
@@ -59,7 +59,7 @@ def main():
         _, yx = syn.make_buoys(grid, nP, seed=1234, frac=0.6)
         yx = yx[:a.buoys]
         ji = syn.regular_host_cell(grid, yx).astype(np.int64)
-        vert = orc.vertices_of(ji)
+        vert = vertices_of(ji)
         u, v, sic = syn.make_fields(grid, K=K, seed=2024, umax=0.3, drift=0.05)
         first = np.zeros(a.buoys, dtype=np.int64); last = np.full(a.buoys, 10**9, dtype=np.int64)
         t0 = time.perf_counter()
