@@ -94,9 +94,7 @@ int sitrk_set_params(sitrk_t *h, double rdt, int uv_strategy, double rmin_conc);
  * cells it takes around their bounding box; "xcd_group" (0..4096, default 16): runs of that many consecutive workgroups of the
  * fused kernel share an XCD (its L2); "step_block" (256/512/1024): workgroup size of the one-record kernel; "fuse" (1..32):
  * consecutive resident records advanced per launch by sitrk_run (loop interchange: the buoys are independent, each lane keeps
- * its buoy in registers across the records); "lat_max" (default 300000, 0 = never): buoy sets up to this size run the fused
- * kernel's latency form (branch-free cell test, crossing evaluated speculatively next to it: scheduled for one wave's chain
- * instead of for instruction issue -- what bounds a set that gives the chip a wave or two per SIMD). */
+ * its buoy in registers across the records). */
 int sitrk_set_tuning(sitrk_t *h, const char *knob, int value);
 
 /* ---- model records (u_ice, v_ice, siconc) -------------------------------
@@ -181,8 +179,6 @@ int sitrk_run(sitrk_t *h, int slot0, int jrec0, int nsteps);
  * they advanced in total (a launch is cut short at a re-sort and at the end of a run), and one-record launches of
  * advect_step_kernel.  Any pointer may be NULL.  bench.py prices its roofline per launch from these. */
 int sitrk_launch_stats(sitrk_t *h, int reset, int64_t *fused_launches, int64_t *fused_records, int64_t *step_launches);
-/* how many of those fused launches (since the last reset of sitrk_launch_stats) ran the kernel's latency form ("lat_max") */
-int sitrk_lat_launches(sitrk_t *h, int64_t *lat_launches);
 
 /* Current state in the caller's buoy order (any pointer may be NULL):
  * yx (nP,2) current position; jiT (nP,2) = vJIt; alive (nP) = iAlive;

@@ -41,7 +41,6 @@ _SIGNATURES = {
     "sitrk_stage_submit": (_int, [_vp, _int, _int, _int]),
     "sitrk_stage_release": (_int, [_vp]),
     "sitrk_launch_stats": (_int, [_vp, _int, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
-    "sitrk_lat_launches": (_int, [_vp, C.POINTER(_i64)]),
     "sitrk_buoy_rows": (_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sitrk_push_record_rows": (_int, [_vp, _int, _int, _int, _vp, _vp, _vp]),
     "sitrk_commit_record_rows": (_int, [_vp, _int, _int, _int]),
@@ -264,10 +263,9 @@ class Context:
         self._chk(self._L.sitrk_stage_submit(self._h, int(slot), int(j0), int(j0) + int(self._staged_rows)))
 
     def launch_stats(self, reset=False):
-        a, b, c, d = _i64(0), _i64(0), _i64(0), _i64(0)
-        self._chk(self._L.sitrk_lat_launches(self._h, C.byref(d)))
+        a, b, c = _i64(0), _i64(0), _i64(0)
         self._chk(self._L.sitrk_launch_stats(self._h, int(bool(reset)), C.byref(a), C.byref(b), C.byref(c)))
-        return {"fused_launches": a.value, "fused_records": b.value, "step_launches": c.value, "lat_launches": d.value}
+        return {"fused_launches": a.value, "fused_records": b.value, "step_launches": c.value}
 
     def buoy_rows(self):
         """(jmin, jmax) of the host rows of the buoys still alive; jmin > jmax when there is none."""

@@ -252,10 +252,6 @@ SITRK_API int sitrk_set_tuning(sitrk_t *h, const char *knob, int value)
         h->xcd_group = value;
         return SITRK_OK;
     }
-    else if (!strcmp(knob, "lat_max")) {
-        if (value < 0) return fail(h, SITRK_EINVAL, "sitrk_set_tuning: lat_max must be >= 0");
-        h->lat_max = value;
-    }
     else if (!strcmp(knob, "patch_margin")) {
         if (value < 0 || value > 64) return fail(h, SITRK_EINVAL, "sitrk_set_tuning: patch_margin must be 0..64");
         h->patch_margin = value;
@@ -783,7 +779,7 @@ static int f32_class_for(double rdt)
 }
 
 template <typename FT>
-static bool launch_run(sitrk_ctx *h, const RunArgs &ra)          // returns whether the latency form was launched
+static void launch_run(sitrk_ctx *h, const RunArgs &ra)
 {
     dim3 grid(nblocks(ra.s.nP, kRunBlock)), block(kRunBlock);
     // dynamic LDS: tables + the patch's F-points
@@ -802,14 +798,8 @@ static bool launch_run(sitrk_ctx *h, const RunArgs &ra)          // returns whet
             else hipLaunchKernelGGL((KERNEL<FT, 0, false>), grid, block, lds, h->stream, ra);             \
         }                                                                                                 \
     } while (0)
-    // small sets: the latency form (same results; advect_run_kernel's comment).  It reads the patch speculatively, so it needs one.
-    if (!windowed && h->uv_strategy == 1 && h->lat_max > 0 && ra.s.nP <= (int64_t)h->lat_max && ra.patch_cells >= 64) {
-        hipLaunchKernelGGL((advect_run_kernel<FT, 1, false, true>), grid, block, lds, h->stream, ra);
-        return true;
-    }
     SITRK_LAUNCH_RUN(advect_run_kernel);
 #undef SITRK_LAUNCH_RUN
-    return false;
 }
 
 SITRK_API int sitrk_run(sitrk_t *h, int slot0, int jrec0, int nsteps)
@@ -868,9 +858,9 @@ SITRK_API int sitrk_run(sitrk_t *h, int slot0, int jrec0, int nsteps)
             const char *slab = slab_of(h, slot);
             ra.u[r] = slab; ra.v[r] = slab + n * es; ra.kill9[r] = h->kill9 + (size_t)slot * n;
         }
-        const bool lat = (h->dtype == SITRK_F64) ? launch_run<double>(h, ra) : launch_run<float>(h, ra);
+        if (h->dtype == SITRK_F64) launch_run<double>(h, ra);
+        else launch_run<float>(h, ra);
         HIPCHK(hipGetLastError());
-        if (lat) h->n_lat_launches++;
         int rc = launch_mark(h, used, m);
         if (rc) return rc;
         h->steps_since_sort += m;
@@ -888,15 +878,7 @@ SITRK_API int sitrk_launch_stats(sitrk_t *h, int reset, int64_t *fused_launches,
     if (fused_launches) *fused_launches = h->n_fused_launches;
     if (fused_records) *fused_records = h->n_fused_records;
     if (step_launches) *step_launches = h->n_step_launches;
-    if (reset) h->n_fused_launches = h->n_fused_records = h->n_step_launches = h->n_lat_launches = 0;
-    return SITRK_OK;
-}
-
-SITRK_API int sitrk_lat_launches(sitrk_t *h, int64_t *lat_launches)
-{
-    NEED(h, "null handle");
-    NEED(lat_launches, "sitrk_lat_launches: null output");
-    *lat_launches = h->n_lat_launches;
+    if (reset) h->n_fused_launches = h->n_fused_records = h->n_step_launches = 0;
     return SITRK_OK;
 }
 

@@ -165,37 +165,6 @@ __device__ __forceinline__ bool inside_quad_hot(double y, double x, pt q0, pt q1
     return inside;
 }
 
-// The same filtered test with NO branch per edge: all four edges are evaluated for every lane and masked by the edge's
-// range condition -- more instructions, no exec-mask bookkeeping and one long basic block the scheduler can interleave
-// with independent work.  For the latency form of the fused kernel (small buoy sets: a wave or two per SIMD, where one
-// wave's dependent chain, not instruction issue, sets the pace).  Same results: an edge whose range condition is false
-// contributes nothing in either form.  `decided` = every contributing edge was decided by the filter.
-__device__ __forceinline__ bool inside_quad_hot_flat(double y, double x, pt q0, pt q1, pt q2, pt q3, double eps_mg, bool &decided)
-{
-    const double mx = __builtin_fma(fabs(x), 0x1p-48, eps_mg);
-    const bool g0 = y > q0.y, g1 = y > q1.y, g2 = y > q2.y, g3 = y > q3.y;
-    const bool l0 = x <= q0.x, l1 = x <= q1.x, l2 = x <= q2.x, l3 = x <= q3.x;
-    bool inside = false;
-    decided = true;
-#define SITRK_EDGE_FLAT(A, B, gA, gB, lA, lB)                                         \
-    {                                                                                 \
-        const bool cond = (gA != gB) & (lA | lB);                                     \
-        const double c = B.y - A.y;                                                   \
-        const double p = (y - A.y) * (B.x - A.x);                                     \
-        const double E = __builtin_fma(x - A.x, c, -p);                               \
-        const bool dec = fabs(E) > __builtin_fma(fabs(c), mx, 0x1p-1000);             \
-        const bool neg = __double2hiint(E) < 0;                                       \
-        decided = decided & (!cond | dec);                                            \
-        inside = inside != (cond & dec & (neg == gA));                                \
-    }
-    SITRK_EDGE_FLAT(q0, q1, g0, g1, l0, l1)
-    SITRK_EDGE_FLAT(q1, q2, g1, g2, l1, l2)
-    SITRK_EDGE_FLAT(q2, q3, g2, g3, l2, l3)
-    SITRK_EDGE_FLAT(q3, q0, g3, g0, l3, l0)
-#undef SITRK_EDGE_FLAT
-    return inside;
-}
-
 // Python-style index: a negative index wraps, as numpy does for the reference
 // (e.g. pY[jbl-1,ibl] with jbl = 0, tracking.py:219).  Indices >= n cannot occur
 // for the cells the library accepts (1 <= jT <= Nj-2, 1 <= iT <= Ni-2).

@@ -64,7 +64,6 @@ struct sitrk_ctx {
     int patch_kb = 16;                  // fused kernel: LDS bytes per workgroup for its geometry patch (0 = none, all reads global)
     int xcd_group = 16;                 // fused kernel: runs of that many consecutive workgroups on one XCD (0/1 = hardware order)
     int patch_margin = 8;               // ... and the widest margin of cells around the buoys' bounding box it may take
-    int lat_max = 300000;               // fused kernel: buoy sets up to this size run its latency form (0 = never); see advect_run_kernel
 
     // records
     int nslots = 0, dtype = 0;
@@ -89,7 +88,7 @@ struct sitrk_ctx {
     // at most one row per record): what a partly uploaded slot is checked against
     int band_jmin = 0, band_jmax = -1, band_age = -1;      // band_age < 0: not evaluated since sitrk_set_buoys
     // launch accounting (sitrk_launch_stats)
-    long long n_fused_launches = 0, n_fused_records = 0, n_step_launches = 0, n_lat_launches = 0;
+    long long n_fused_launches = 0, n_fused_records = 0, n_step_launches = 0;
 
     // buoys
     int64_t nP = 0;

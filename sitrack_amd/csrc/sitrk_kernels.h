@@ -619,7 +619,6 @@ __device__ __forceinline__ void load_ctx_lds(const StepArgs &a, const Patch &pa,
 // resolve_crossing_tab() with every point read from the patch: same predicates, same operands, same order.
 // tabL row kc-1 (16 ints like a row of tab): [0] va [1] vb [2] eA [3] eB  LDS byte offsets relative to the host cell's
 // biased address (i.e. + kLdsBias); [4] S [5] A [6] B  LDS byte increments to the destination cell's record
-template <bool LAZY = true>
 __device__ __forceinline__ void resolve_crossing_lds(pt P1, pt P2, pt bl, pt br, pt ur, pt ul, unsigned lo, unsigned k9,
                                                      const int *__restrict__ tab, const int *__restrict__ tabL, int &dcell, int &dk,
                                                      int &dlo, bool &killed)
@@ -637,14 +636,9 @@ __device__ __forceinline__ void resolve_crossing_lds(pt P1, pt P2, pt bl, pt br,
     const pt eA = lds_pt_at(lo + (unsigned)l0.z), eB = lds_pt_at(lo + (unsigned)l0.w);
     bool hitA = ccw(P1, va, eA) != ccw(P2, va, eA);
     bool hitB = ccw(P1, vb, eB) != ccw(P2, vb, eB);
-    if (LAZY) {
-        if (hitA || hitB) {
-            hitA = hitA && (ccw(P1, P2, va) != ccw(P1, P2, eA));
-            hitB = hitB && (ccw(P1, P2, vb) != ccw(P1, P2, eB));
-        }
-    } else {                                             // latency form: no branch, both halves for every lane
-        hitA = hitA & (ccw(P1, P2, va) != ccw(P1, P2, eA));
-        hitB = hitB & (ccw(P1, P2, vb) != ccw(P1, P2, eB));
+    if (hitA || hitB) {
+        hitA = hitA && (ccw(P1, P2, va) != ccw(P1, P2, eA));
+        hitB = hitB && (ccw(P1, P2, vb) != ccw(P1, P2, eB));
     }
     dcell = hitA ? r1.y : (hitB ? r1.z : r1.x);
     dk = hitA ? r2.x : (hitB ? r2.y : r1.w);
@@ -666,18 +660,9 @@ static constexpr int kRunBlock = SITRK_RUN_BLOCK;
 #define SITRK_RUN_WAVES_WINDOW 6        // the form with per-buoy record windows carries two more registers: 9 spilled at 7 waves (13-25
                                         // with the window packed into one register, as a single test, or as a predicate on the body)
 #endif
-// LAT = the LATENCY FORM for small buoy sets (sitrk_run picks it when the set gives the chip a wave or two per SIMD): then
-// the pace is set by ONE wave's dependent chain per record (4 400 cycles for ~350 instructions in the form above: measured
-// flat from 25 000 to 100 000 buoys on C2, profiles/r03c_c2_latency_probe.txt), not by instruction issue, which is three
-// quarters idle.  Same operations on the same operands, scheduled for latency instead of issue: the cell test evaluates
-// its four edges without a branch per edge, and CrossedEdge / NewHostCell are evaluated SPECULATIVELY for every lane next
-// to the cell test (both only need the new position) instead of behind it -- one long basic block whose independent
-// chains the scheduler interleaves; only the bookkeeping of lanes that really crossed stays in a divergent region.
-// More vector instructions per record, far fewer scalar ones and stalls.  uv_strategy 1, no record windows.
-template <typename FT, int UVS, bool WINDOW, bool LAT = false>
-__global__ __launch_bounds__(kRunBlock, LAT ? 3 : (WINDOW ? SITRK_RUN_WAVES_WINDOW : SITRK_RUN_WAVES)) void advect_run_kernel(RunArgs ra)
+template <typename FT, int UVS, bool WINDOW>
+__global__ __launch_bounds__(kRunBlock, WINDOW ? SITRK_RUN_WAVES_WINDOW : SITRK_RUN_WAVES) void advect_run_kernel(RunArgs ra)
 {
-    static_assert(!LAT || (UVS == 1 && !WINDOW), "the latency form exists for iUVstrategy = 1 without record windows");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *s_tab = (int *)smem;                            // CrossTab, 64 ints
     int *s_tabL = s_tab + 64;                            // 4 rows of 16 ints (7 used)
@@ -761,81 +746,6 @@ __global__ __launch_bounds__(kRunBlock, LAT ? 3 : (WINDOW ? SITRK_RUN_WAVES_WIND
     const char *ub_next = (const char *)ra.u[0], *vb_next = (const char *)ra.v[0], *kb_next = (const char *)ra.kill9[0];
     double k1000 = 1000.;                                // div1000's constant, kept in scalar registers
     asm volatile("" : "+s"(k1000));
-    if constexpr (LAT) {
-        // a lane outside the patch evaluates the speculative crossing on cell (2,2) of the patch (any address inside it
-        // will do: the result is discarded, such a lane resolves its crossings through global memory below)
-        const unsigned lo_safe = geo_la + patch_off(pa, 2, 2);
-#pragma unroll 1
-        for (int r = 0; r < ra.nrec; r++) {
-            const int jrec = a.jrec + r;
-            const char *ub = ub_next, *vb = vb_next, *kb = kb_next;
-            const int rn = (r + 1 < ra.nrec) ? r + 1 : r;
-            ub_next = (const char *)ra.u[rn]; vb_next = (const char *)ra.v[rn]; kb_next = (const char *)ra.kill9[rn];
-            FT fu0 = *(const FT *)(ub + x.o1 - sizeof(FT)), fu1 = *(const FT *)(ub + x.o1);
-            FT fv0 = *(const FT *)(vb + (x.o1 - (unsigned)a.Ni * (unsigned)sizeof(FT))), fv1 = *(const FT *)(vb + x.o1);
-            unsigned k9 = *(const uint8_t *)(kb + (x.o1 >> (sizeof(FT) == 4 ? 2 : 3)));
-            // velocity pick (:427-441), both halves of both tests for every lane
-            const bool sFV = (x.ori & 1u) != 0, sFU = (x.ori & 2u) != 0;
-            const bool llum1 = (ccw(P, x.V01, x.V11) != sFV) & (ccw(P, x.F11, x.V01) != ccw(P, x.F11, x.V11));
-            const bool llvm1 = (ccw(P, x.U10, x.U11) != sFU) & (ccw(P, x.F11, x.U10) != ccw(P, x.F11, x.U11));
-            pin_load(fu0); pin_load(fv0);
-            const FT su = llum1 ? fu0 : fu1, sv = llvm1 ? fv0 : fv1;
-            const double dx = (double)su * a.rdt, dy = (double)sv * a.rdt;          // :452-458
-            // x / 1000 without a division (sitrk_geom.h: div1000_core); ONE never-taken branch for both components
-            bool okx, oky;
-            if (sizeof(FT) == 4) {
-                okx = __builtin_amdgcn_classf((float)su, ra.f32_class); oky = __builtin_amdgcn_classf((float)sv, ra.f32_class);
-            } else {
-                okx = ((((unsigned)__double2hiint(dx) >> 20) & 0x7ffu) - 123u) < 1800u;
-                oky = ((((unsigned)__double2hiint(dy) >> 20) & 0x7ffu) - 123u) < 1800u;
-            }
-            double qx = div1000_core(dx, k1000, true), qy = div1000_core(dy, k1000, true);
-            if (__builtin_expect(!(okx & oky), 0)) {
-                double tx = dx, ty = dy;
-                asm volatile("" : "+v"(tx), "+v"(ty));
-                qx = okx ? qx : tx / 1000.;
-                qy = oky ? qy : ty / 1000.;
-            }
-            pt Pn;
-            Pn.x = P.x + qx;
-            Pn.y = P.y + qy;
-            moved = true;
-            // cell test (:466), four edges without branches, and -- next to it, not behind it -- CrossedEdge / NewHostCell /
-            // the destination's Survive bit for every lane (:474-484)
-            bool decided;
-            bool inside = inside_quad_hot_flat(Pn.y, Pn.x, x.F00, x.F01, x.F11, x.F10, a.eps_mg, decided);
-            int dcell, dk, dlo;
-            bool killed_f;
-            pin_load(k9);
-            resolve_crossing_lds<false>(P, Pn, x.F00, x.F01, x.F11, x.F10, inl ? lo : lo_safe, k9, s_tab, s_tabL, dcell, dk, dlo, killed_f);
-            if (__builtin_expect(!decided, 0)) inside = inside_quad(Pn.y, Pn.x, x.F00, x.F01, x.F11, x.F10);
-            bool killed = false;
-            if (!inside) {
-                const unsigned kcell = x.o1 / (unsigned)sizeof(FT);
-                if (inl) {
-                    killed = killed_f;
-                    lo += (unsigned)dlo;
-                } else {
-                    resolve_crossing_tab(P, Pn, x.F00, x.F01, x.F11, x.F10, kcell * (unsigned)sizeof(CellGeo), k9, gb, s_tab, dcell, dk, killed);
-                }
-                c += dcell;
-                recelled = true;
-                const int crel2 = c - porg;
-                if (!inl) lo = geo_la + patch_off(pa, crel2 >> 16, crel2 & 0xffff);
-                inl = patch_covers(pa, crel2 >> 16, crel2 & 0xffff);
-                if (inl) load_ctx_lds<sizeof(FT)>(a, pa, gb, kcell + (unsigned)dk, lo, x);
-                else load_ctx<sizeof(FT)>(a, gb, kcell + (unsigned)dk, x);
-            }
-            P = Pn;
-            if (killed) {
-                c |= SITRK_DEAD_BIT;
-                unsigned tk = threadIdx.x;
-                asm volatile("" : "+v"(tk));
-                a.kill_rec[(int64_t)blk * kRunBlock + tk] = jrec;
-                break;
-            }
-        }
-    } else
 #pragma unroll 1
     for (int r = 0; r < ra.nrec; r++) {
         const int jrec = a.jrec + r;

@@ -60,8 +60,7 @@ def one_case(rng, idx, nstrat=2):
     trk.ctx.set_tuning(fuse=fuse, sort_tile=tile, nt_state=int(rng.integers(0, 2)), xcd_remap=int(rng.integers(0, 2)),
                        step_block=int(rng.choice([256, 512, 1024])),
                        patch_kb=int(rng.choice([0, 2, 16, 40])), patch_margin=int(rng.choice([0, 2, 8])),
-                       xcd_group=int(rng.choice([0, 3, 16])),
-                       lat_max=int(rng.choice([0, 10**9])))          # regular / latency form of the fused kernel
+                       xcd_group=int(rng.choice([0, 3, 16])))
     trk.set_buoys(yx, ji, first, last, sort=bool(rng.random() < 0.8))
     trk.ctx.set_resort(int(rng.choice([0, 3, 17])))
     g2 = dict(grid); g2["tmask"] = tmask
@@ -85,9 +84,8 @@ def one_case(rng, idx, nstrat=2):
     assert np.array_equal(st["vJIt"], ref.jiT), ("cell", idx)
     assert np.array_equal(st["iAlive"], ref.alive), ("alive", idx)
     assert np.array_equal(st["kill_rec"] >= 0, ref.alive == 0), ("kill_rec", idx)
-    desc = "grid %dx%d warp %.1f dkm %.1f nP %d Nt %d K %d strat %d %s win %d fuse %d tile %d forms %s: crossings %d dead %d" % (
-        Nj, Ni, warp, dkm, n, Nt, K, strat, np.dtype(fdt).name, windowed, fuse, tile, trk.ctx.launch_stats().get("lat_launches", "?"),
-        ref.ncross, int((ref.alive == 0).sum()))
+    desc = "grid %dx%d warp %.1f dkm %.1f nP %d Nt %d K %d strat %d %s win %d fuse %d tile %d: crossings %d dead %d" % (
+        Nj, Ni, warp, dkm, n, Nt, K, strat, np.dtype(fdt).name, windowed, fuse, tile, ref.ncross, int((ref.alive == 0).sum()))
     trk.close()
     return desc
 

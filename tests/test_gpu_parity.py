@@ -628,11 +628,7 @@ def test_tuning_knobs_do_not_change_results():
                   {"sort_tile": 5 * 256 + 7, "nt_state": 1, "xcd_remap": 1},
                   # the fused kernel's LDS patch: none, tiny (most buoys leave it: global fallback), large; XCD grouping; one-record launches
                   {"patch_kb": 0}, {"patch_kb": 1, "patch_margin": 0}, {"patch_kb": 60, "patch_margin": 40}, {"xcd_group": 0},
-                  {"xcd_group": 5, "patch_kb": 3}, {"fuse": 1}, {"fuse": 2, "patch_kb": 2},
-                  # small sets run the fused kernel's latency form by default (lat_max = 300 000 buoys): the regular form
-                  # (what C3 runs) with the same patch variants, and the latency form with a tiny / no patch
-                  {"lat_max": 0}, {"lat_max": 0, "patch_kb": 1, "patch_margin": 0}, {"lat_max": 0, "patch_kb": 0, "xcd_group": 0},
-                  {"lat_max": 10**9, "patch_kb": 2, "patch_margin": 1}, {"lat_max": 10**9, "fuse": 3}):
+                  {"xcd_group": 5, "patch_kb": 3}, {"fuse": 1}, {"fuse": 2, "patch_kb": 2}):
         trk = make_tracker(grid, grid["tmask"], 3)
         found, ji, _ = sit.FindContainingCell(yx, syn.nearest_t_plane(grid, yx), ctx=trk.ctx)
         trk.ctx.set_tuning(**knobs)
