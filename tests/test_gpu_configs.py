@@ -53,6 +53,13 @@ def test_c3_full_1000_steps_checked_by_the_oracle():
     want = r["valu_inst_per_wave_record"] * r["waves_per_launch"] * (r["records_advanced"] + r["one_record_launches"]) / \
         (r["avg_launch_ms"] * 1e-3 * (r["launches"] + r["one_record_launches"])) / 1e9 / r["peak"]
     assert abs(r["frac"] - want) < 1e-6 * want
+    # round 3: the ceiling weights the instruction classes (4 cycles for the 64-bit ones, 2 for the rest), the instruction count
+    # is the one of THIS run's launch length (fixed per launch + per record), both clocks are stated, and SURVEY's closed-form
+    # bytes charged to every record of a launch come out above the HBM peak (the launch reads state and geometry once)
+    assert 2.0 < r["cycles_per_valu_inst"] < 4.0 and abs(r["peak"] - 1024 * 2.4 / r["cycles_per_valu_inst"]) < 1e-6 * r["peak"]
+    assert r["frac_uniform_4_cycles"] > r["frac"] and r["frac_at_held_clock"] > r["frac"] and 1.5 < r["clock_held_ghz"] <= 2.4
+    assert "fixed per launch" in r["valu_inst_source"] and 190 < r["valu_inst_per_wave_record"] < 230
+    assert r["hbm"]["survey_formula_frac"] > 1.0 and r["hbm"]["frac"] < 0.5
 
 
 @pytest.fixture(scope="module")
