@@ -235,11 +235,19 @@ class Comm:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.backend = None
         self.dist = None
-        if self.world > 1:
+        # SITRK_FORCE_DIST=1: ONE rank takes every multi-rank code path (process group of one, RCCL collectives with themselves):
+        # the rehearsal a one-GPU box allows for the nccl branches, which RCCL refuses to run with two ranks on one device
+        force = self.world == 1 and os.environ.get("SITRK_FORCE_DIST") == "1"
+        if self.world > 1 or force:
             import torch
             import torch.distributed as dist
             self.backend = os.environ.get("SITRK_DIST_BACKEND", "nccl")
             self.device = int(os.environ.get("SITRK_DEVICE", str(self.local_rank)))
+            if force:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29541")
+                os.environ.setdefault("RANK", "0")
+                os.environ.setdefault("WORLD_SIZE", "1")
             if self.backend == "nccl":
                 torch.cuda.set_device(self.device)
                 dist.init_process_group("nccl", device_id=torch.device("cuda", self.device))
@@ -250,6 +258,11 @@ class Comm:
             self.device = None
 
     @property
+    def multi(self):
+        """the multi-rank code paths are in use (several ranks, or one rank rehearsing them)"""
+        return self.dist is not None
+
+    @property
     def root(self):
         return self.rank == 0
 
@@ -257,21 +270,21 @@ class Comm:
         return buoy_range(n, self.rank, self.world)
 
     def bcast_obj(self, obj, src=0):
-        if self.world == 1:
+        if self.dist is None:
             return obj
         box = [obj if self.rank == src else None]
         self.dist.broadcast_object_list(box, src=src)
         return box[0]
 
     def allgather_obj(self, obj):
-        if self.world == 1:
+        if self.dist is None:
             return [obj]
         out = [None] * self.world
         self.dist.all_gather_object(out, obj)
         return out
 
     def sum_int(self, n):
-        if self.world == 1:
+        if self.dist is None:
             return int(n)
         return int(sum(self.allgather_obj(int(n))))
 
@@ -282,7 +295,7 @@ class Comm:
         """Every rank contributes a tuple of arrays with one common (rank-dependent) number of rows; every rank gets back
         the tuple of their concatenations in rank order.  Tensor collectives (sizes first, then one padded all-gather per
         array): what SeedInit's per-range results travel with -- 10^7..10^8 seeds are GBs, not something to pickle."""
-        if self.world == 1:
+        if self.dist is None:
             return tuple(np.asarray(a) for a in arrays)
         import torch
         n = int(np.shape(arrays[0])[0])
@@ -306,7 +319,7 @@ class Comm:
         W, me = self.world, self.rank
         narr = len(chunks[0])
         send_n = [int(np.shape(chunks[d][0])[0]) for d in range(W)]
-        if W == 1:
+        if self.dist is None:
             return tuple(np.asarray(a) for a in chunks[0])
         cnt = torch.tensor(send_n, dtype=torch.int64, device=self._dev())
         rcv = torch.empty(W, dtype=torch.int64, device=self._dev())
@@ -344,7 +357,7 @@ class Comm:
 
     def allreduce_sum(self, a):
         """element-wise sum over the ranks of an int64 / float64 array (returned on every rank)"""
-        if self.world == 1:
+        if self.dist is None:
             return np.asarray(a)
         import torch
         t = torch.from_numpy(np.ascontiguousarray(a)).to(self._dev())
@@ -353,7 +366,7 @@ class Comm:
 
     def bcast_arrays(self, arrays, src=0):
         """tuple of numpy arrays from `src` to everyone as tensors (shapes and dtypes travel as a small object first)"""
-        if self.world == 1:
+        if self.dist is None:
             return arrays
         import torch
         meta = self.bcast_obj([(np.asarray(a).shape, np.asarray(a).dtype.str) for a in arrays] if self.rank == src else None, src)
@@ -368,13 +381,13 @@ class Comm:
 
     def gather_rows(self, local, n_total):
         """rank 0: rows of every rank concatenated in rank (= buoy) order; others: None."""
-        if self.world == 1:
+        if self.dist is None:
             return local
         return gather_ranges(local, n_total)
 
     def deliver_record(self, ctx, slot, fields):
         """`fields` = (u, v, sic) arrays on rank 0, None elsewhere: make the record resident in `slot` everywhere."""
-        if self.world == 1:
+        if self.dist is None:
             ctx.push_record(slot, *fields)
         elif self.backend == "nccl":
             slab = pack_slab(*fields, dtype=ctx.field_dtype) if self.root else None

@@ -217,7 +217,7 @@ def main(argv=None):
     comm = Comm()
     say = print if comm.root else (lambda *args, **kw: None)
     say('\n *** SITRACK ice particule tracker, GPU build; NetCDF backend = ' + ncio.backend()
-        + ('; %d ranks (%s)' % (comm.world, comm.backend) if comm.world > 1 else ''))
+        + ('; %d ranks (%s)' % (comm.world, comm.backend) if comm.multi else ''))
     say(' *** SI3 file =>', cf_uv, '\n *** mesh_mask =>', cf_mm, '\n *** seeding  =>', fNCseed, jrecSeed)
 
     cdtbin, csfkm = seed_name_tokens(path.basename(fNCseed))
@@ -239,7 +239,7 @@ def main(argv=None):
         for cd in ('seed', 'nc', 'npz'):
             os.makedirs(cd, exist_ok=True)
 
-    ctx = _lib.Context(a.device if comm.world == 1 else comm.device)
+    ctx = _lib.Context(comm.device if comm.multi else a.device)
     tk = clk.now()
     imaskt, xlatT, xlonT, xYt, xXt, xYf, xXf, xResKM = ncio.GetModelGrid(cf_mm, ctx=ctx)
     if iUVstrategy >= 1:
@@ -295,13 +295,13 @@ def main(argv=None):
 
     # ---- device state.  Under torchrun every rank owns a contiguous range of the buoys ordered by host row, i.e. a
     #      latitude band: with row-band ingest each rank then reads only its own rows of every record, no collective.
-    order = np.arange(nP) if comm.world == 1 else np.argsort(vJIt[:, 0], kind='stable')
+    order = np.argsort(vJIt[:, 0], kind='stable') if comm.multi else np.arange(nP)
     lo, hi = comm.range(nP)
     part = {"order": order, "mine": order[lo:hi]}          # who owns what; re-made by rebalance()
     mine = part["mine"]
 
     def to_caller_order(rows):            # rows gathered in rank order -> the caller's buoy order
-        if rows is None or comm.world == 1:
+        if rows is None or not comm.multi:
             return rows
         out = np.empty_like(rows)
         out[part["order"]] = rows
@@ -345,7 +345,7 @@ def main(argv=None):
         return lFull or (lUse2DTime and jrec in ends)
 
     bcast = None
-    if a.full_records and comm.world > 1 and comm.backend == "nccl":
+    if a.full_records and comm.multi and comm.backend == "nccl":
         from .distributed import RecordBroadcaster
         bcast = RecordBroadcaster(ctx)                 # rank 0 reads; one RCCL broadcast per record, overlapped with the stepping
     batches, jt = [], 0
@@ -376,7 +376,7 @@ def main(argv=None):
                     ctx.stage_fill(slot, j0, j1 - j0, lambda *outs: records.fields_rows_into(jrec, j0, j1, outs))
                 else:
                     ctx.commit_record_rows(slot, 0, 0)                  # no live buoy: nothing to read
-            elif comm.world == 1:
+            elif not comm.multi:
                 ctx.stage_fill(slot, 0, Nj, lambda *outs: records.fields_rows_into(jrec, 0, Nj, outs))   # the whole record (:372-374)
             elif bcast is not None:
                 bcast.deliver(slot, records.fields(jrec) if comm.root else None)
@@ -430,7 +430,7 @@ def main(argv=None):
     due, since = [], 0
     for (jt0, m) in batches:              # after which batches the ranks re-balance: a function of the record count alone
         since += m
-        due.append(comm.world > 1 and a.rebalance > 0 and since >= a.rebalance)
+        due.append(comm.multi and a.rebalance > 0 and since >= a.rebalance)
         if due[-1]:
             since = 0
     if due:

@@ -585,6 +585,36 @@ def test_cli_two_ranks_equals_one(tmp_path, monkeypatch, two_d_time, extra):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("two_d_time,extra", [(False, ["--full-records"]), (False, ["--rebalance", "3"]), (True, ["--rebalance", "4"]), (True, [])])
+def test_cli_one_rccl_rank_through_the_multi_rank_paths(tmp_path, monkeypatch, two_d_time, extra):
+    """The `nccl` branches of the driver -- RCCL tensor all-gathers of the per-range SeedInit results, the seed cache by tensor
+    broadcast, `RecordBroadcaster` (in-place slab broadcast on a communication stream), tensor gathers at output records, and the
+    re-balancing all-to-all (`all_to_all_single`) with `sitrk_restore_state` -- rehearsed with ONE RCCL rank (SITRK_FORCE_DIST=1:
+    a process group of one; RCCL refuses two ranks per device and the box has one GPU): the files must equal the plain
+    single-process run's in every variable.  With more than one RCCL rank these paths are unrun."""
+    import subprocess
+    import sys
+    d1, d2 = tmp_path / "one", tmp_path / "forced"
+    d1.mkdir(); d2.mkdir()
+    c = make_case(str(tmp_path), two_d_time=two_d_time)
+    argv = ["-i", c["si3"], "-m", c["mm"], "-s", c["seed"], "-N", "TEST4"] + ([] if two_d_time else ["-F"])
+    monkeypatch.chdir(d1)
+    one = drv.main(argv + ["--full-records"])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = __import__("socket").socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SITRK_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PYTHONPATH=root)
+    r = subprocess.run([sys.executable, os.path.join(root, "si3_part_tracker.py")] + argv + extra, cwd=str(d2), env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "1 ranks (nccl)" in r.stdout or "ranks (nccl)" in r.stdout, r.stdout[:600]
+    for f in one["files"]:
+        a = ncio.LoadNCdata(str(d1 / f), krec=-1, lmask=True)
+        b = ncio.LoadNCdata(str(d2 / f), krec=-1, lmask=True)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), f
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("extra", [[], ["--rebalance", "3"], ["--full-records"]])
 def test_cli_rank_without_buoys(tmp_path, monkeypatch, extra):
     """Three ranks, two seeds: the last rank owns no buoy from the start (and with --rebalance ranks lose and gain all
