@@ -88,7 +88,8 @@ int sitrk_set_params(sitrk_t *h, double rdt, int uv_strategy, double rmin_conc);
  * contiguous chunk of the cell-sorted buoys; "nt_state" (0/1): non-temporal loads/stores for
  * the once-per-step position/cell streams; "sort_tile" (tile_j*256 + tile_i, 0 = row-major):
  * order of the cell sort, tile-major tiles of tile_j x tile_i cells; "locate_bruteforce" (0/1):
- * SeedInit scans the whole grid per seed like the reference instead of the bounding-sphere search;
+ * SeedInit scans the whole grid per seed like the reference instead of the bounding-sphere search; "survive_tile" (0/1): derive a
+ * record's Survive bytes with the LDS-tile kernel even where the register-rolling one applies (meshes with Ni % 4 == 0);
  * "patch_kb" (0..63, default 16) / "patch_margin" (0..64, default 8): KB of LDS per workgroup that the fused kernel may fill with
  * the F-points of the cells around its buoys (0 = none: every geometry read goes to global memory), and the widest margin of
  * cells it takes around their bounding box; "xcd_group" (0..4096, default 16): runs of that many consecutive workgroups of the

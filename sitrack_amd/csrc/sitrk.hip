@@ -226,6 +226,7 @@ SITRK_API int sitrk_set_tuning(sitrk_t *h, const char *knob, int value)
     int bit = 0;
     if (!strcmp(knob, "xcd_remap")) bit = TUNE_XCD_REMAP;
     else if (!strcmp(knob, "nt_state")) bit = TUNE_NT_STATE;
+    else if (!strcmp(knob, "survive_tile")) bit = TUNE_SURVIVE_TILE;
     else if (!strcmp(knob, "step_block")) {          // workgroup size of advect_step_kernel
         if (value != 256 && value != 512 && value != 1024) return fail(h, SITRK_EINVAL, "sitrk_set_tuning: step_block must be 256, 512 or 1024");
         h->step_block = value;
@@ -339,24 +340,40 @@ static int launch_mark(sitrk_ctx *h, const int *slots, int nslots_used)
     return SITRK_OK;
 }
 
+// Survive bytes + packed neighbourhoods of rows [j0,j1) from the siconc rows [v0,v1) of `sic` (device pointer, f64 or f32), one pass
+static int launch_survive(sitrk_ctx *h, bool f64, const void *sic, int8_t *kill, uint8_t *kill9, int j0, int j1, int v0, int v1)
+{
+    if ((h->Ni & 3) == 0 && !(h->tune & TUNE_SURVIVE_TILE)) {
+        // 16-byte aligned rows: the register-rolling form (no LDS, no barriers; sitrk_kernels.h)
+        const dim3 g((unsigned)((h->Ni + kSvRowsCols - 1) / kSvRowsCols), (unsigned)((j1 - j0 + 4 * kSvRowsR - 1) / (4 * kSvRowsR)));
+        if (f64)
+            hipLaunchKernelGGL((survive_kill9_rows_kernel<double>), g, dim3(256), 0, h->stream, h->Nj, h->Ni, j0, j1, v0, v1, h->tmask,
+                               (const double *)sic, h->rmin_conc, kill, kill9);
+        else
+            hipLaunchKernelGGL((survive_kill9_rows_kernel<float>), g, dim3(256), 0, h->stream, h->Nj, h->Ni, j0, j1, v0, v1, h->tmask,
+                               (const float *)sic, h->rmin_conc, kill, kill9);
+    } else {
+        const dim3 grid((unsigned)((h->Ni + kSvTC - 1) / kSvTC), (unsigned)((j1 - j0 + kSvTR - 1) / kSvTR));
+        if (f64)
+            hipLaunchKernelGGL((survive_kill9_kernel<double>), grid, dim3(kSvBlock), 0, h->stream, h->Nj, h->Ni, j0, j1, v0, v1, h->tmask,
+                               (const double *)sic, h->rmin_conc, kill, kill9);
+        else
+            hipLaunchKernelGGL((survive_kill9_kernel<float>), grid, dim3(kSvBlock), 0, h->stream, h->Nj, h->Ni, j0, j1, v0, v1, h->tmask,
+                               (const float *)sic, h->rmin_conc, kill, kill9);
+    }
+    HIPCHK(hipGetLastError());
+    return SITRK_OK;
+}
+
 // derive the Survive bytes of rows [j0,j1) of a slot from its siconc rows [v0,v1) (queued on the compute stream)
 static int derive_mask_rows(sitrk_ctx *h, int slot, int j0, int j1, int v0, int v1)
 {
     const size_t n = (size_t)h->Nj * h->Ni, es = elem_size(h->dtype);
     const char *sic = slab_of(h, slot) + 2 * n * es;
-    int8_t *kill = h->kill + (size_t)slot * n;
     int rc = slot_wait_upload(h, slot);
     if (rc) return rc;
-    // one pass: the Survive bytes of these rows and the 3x3 neighbourhoods of them, one byte per cell, for the fused kernel
-    const dim3 grid((unsigned)((h->Ni + kSvTC - 1) / kSvTC), (unsigned)((j1 - j0 + kSvTR - 1) / kSvTR));
-    uint8_t *kill9 = h->kill9 + (size_t)slot * n;
-    if (h->dtype == SITRK_F64)
-        hipLaunchKernelGGL((survive_kill9_kernel<double>), grid, dim3(kSvBlock), 0, h->stream, h->Nj, h->Ni, j0, j1, v0, v1, h->tmask,
-                           (const double *)sic, h->rmin_conc, kill, kill9);
-    else
-        hipLaunchKernelGGL((survive_kill9_kernel<float>), grid, dim3(kSvBlock), 0, h->stream, h->Nj, h->Ni, j0, j1, v0, v1, h->tmask,
-                           (const float *)sic, h->rmin_conc, kill, kill9);
-    HIPCHK(hipGetLastError());
+    rc = launch_survive(h, h->dtype == SITRK_F64, sic, h->kill + (size_t)slot * n, h->kill9 + (size_t)slot * n, j0, j1, v0, v1);
+    if (rc) return rc;
     h->slot_dirty[slot] = 0;
     return SITRK_OK;
 }
@@ -1280,10 +1297,8 @@ SITRK_API int sitrk_survive_mask(sitrk_t *h, const double *sic, int8_t *mask)
     char *s = (char *)h->scratch;
     HIPCHK(hipMemcpyAsync(s, sic, cells * 8, hipMemcpyHostToDevice, h->stream));
     // the very kernel that derives a resident record's bytes (the packed neighbourhoods go to scratch and are dropped)
-    hipLaunchKernelGGL((survive_kill9_kernel<double>), dim3((unsigned)((h->Ni + kSvTC - 1) / kSvTC), (unsigned)((h->Nj + kSvTR - 1) / kSvTR)),
-                       dim3(kSvBlock), 0, h->stream, h->Nj, h->Ni, 0, h->Nj, 0, h->Nj, h->tmask, (const double *)s, h->rmin_conc,
-                       (int8_t *)(s + b_s), (uint8_t *)(s + b_s + b_m));
-    HIPCHK(hipGetLastError());
+    rc = launch_survive(h, true, s, (int8_t *)(s + b_s), (uint8_t *)(s + b_s + b_m), 0, h->Nj, 0, h->Nj);
+    if (rc) return rc;
     HIPCHK(hipMemcpyAsync(mask, s + b_s, cells, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return SITRK_OK;

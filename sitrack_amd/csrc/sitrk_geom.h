@@ -181,6 +181,7 @@ enum : int {
     TUNE_XCD_REMAP = 1,            // give each XCD a contiguous chunk of the sorted buoys
     TUNE_NT_STATE = 2,             // non-temporal loads/stores for the once-per-step pos/cell streams
     TUNE_LOCATE_BRUTEFORCE = 8,    // SeedInit: whole-grid Haversine scan per seed (the reference's algorithm)
+    TUNE_SURVIVE_TILE = 4,         // derive the Survive bytes with the LDS-tile kernel even where the register-rolling one applies
     TUNE_DIAG_MEMONLY = 16,        // ablation kernels, diagnostic builds only (make DIAG=1)
     TUNE_DIAG_NOCROSS = 32,
 };

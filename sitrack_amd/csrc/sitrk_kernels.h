@@ -177,6 +177,169 @@ __global__ __launch_bounds__(kSvBlock) void survive_kill9_kernel(int Nj, int Ni,
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same two outputs WITHOUT LDS and without barriers, for meshes whose rows are 16-byte aligned (Ni % 4 == 0: every
+// configuration of BASELINE.json): a wavefront walks DOWN a strip of the mesh, one mesh row per iteration, each lane owning
+// four adjacent columns (one 16-byte load of siconc and one 4-byte load of tmask per lane and row; 16 B loads, 4 B stores).
+// A Survive byte needs the rows j-1, j, j+1 of both inputs: they are the last three rows the wave loaded (registers); the
+// columns i-1 and i+1 of a lane's edge cells are the neighbouring lanes' edge values (two shuffles per input and row).
+// The packed neighbourhoods of row j need the Survive bytes of rows j-1..j+1: the last three rows the wave derived.  So row
+// r is loaded, row r-1's Survive bytes are derived, row r-2's outputs are stored.  Lanes 0 and 63 are halo (a strip yields
+// 62 x 4 = 248 columns per row), a chunk of kSvRowsR rows costs 4 extra rows.  Loads run kSvRowsD rows ahead (unconditional,
+// from clamped addresses).  Per row and wave: 38 fp64-class + 105 32-bit vector instructions for 248 cells, against ~1.5
+// wave-instructions per cell of the LDS-tile kernel above, which stays the general form (any Ni).  35 us per 4096^2 record
+// (58 us the LDS-tile kernel, 110 us round 2's two passes): 117 MB -> 3.3 TB/s.
+// Same tests, same order, same left-to-right fp64 sum; same validity rules for row bands.
+// ---------------------------------------------------------------------------
+#ifndef SITRK_SV_R
+#define SITRK_SV_R 16                   // measured at 4096^2 (tools/sv_ab.sh, profiles/r03m_*): 8 / 12 / 16 / 32 / 64 rows per wave = 34.7 / 35.4 /
+#endif                                  // 35.3 / 39.3 / 57.1 us -- more waves beat fewer halo rows; 16 keeps the halo at 25 %
+#ifndef SITRK_SV_D
+#define SITRK_SV_D 4
+#endif
+static constexpr int kSvRowsR = SITRK_SV_R;  // output rows per wave
+static constexpr int kSvRowsD = SITRK_SV_D;  // rows in flight per wave; (kSvRowsR + 4) % kSvRowsD == 0
+static_assert((kSvRowsR + 4) % kSvRowsD == 0, "the row loop is unrolled by the prefetch depth");
+static constexpr int kSvRowsCols = 62 * 4;   // output columns per wave and row
+
+template <typename FT> struct Row4 { FT x, y, z, w; };
+
+template <typename FT>
+__device__ __forceinline__ Row4<FT> sv_load4(const FT *__restrict__ p)
+{
+    Row4<FT> r;
+    if (sizeof(FT) == 4) {
+        const float4 t = *(const float4 *)p;
+        r.x = (FT)t.x; r.y = (FT)t.y; r.z = (FT)t.z; r.w = (FT)t.w;
+    } else {
+        const double2 a = *(const double2 *)p, b = *(const double2 *)(p + 2);
+        r.x = (FT)a.x; r.y = (FT)a.y; r.z = (FT)b.x; r.w = (FT)b.y;
+    }
+    return r;
+}
+
+// lane i <- lane i-1 / lane i+1 across the whole wavefront as ONE vector instruction each (DPP wave_shr:1 / wave_shl:1, gfx9
+// family) instead of a round trip through the LDS crossbar (ds_bpermute + lgkmcnt wait): three such hops sit on every row's
+// dependent chain.  Lane 0 (63) keeps its own value: the strip's halo lanes never use what they would receive.
+__device__ __forceinline__ int sv_up1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int sv_dn1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ float sv_shfl_up(float v) { return __int_as_float(sv_up1(__float_as_int(v))); }
+__device__ __forceinline__ float sv_shfl_dn(float v) { return __int_as_float(sv_dn1(__float_as_int(v))); }
+__device__ __forceinline__ double sv_shfl_up(double v)
+{
+    return __hiloint2double(sv_up1(__double2hiint(v)), sv_up1(__double2loint(v)));
+}
+__device__ __forceinline__ double sv_shfl_dn(double v)
+{
+    return __hiloint2double(sv_dn1(__double2hiint(v)), sv_dn1(__double2loint(v)));
+}
+
+template <typename FT>
+__global__ __launch_bounds__(256) void survive_kill9_rows_kernel(int Nj, int Ni, int j_lo, int j_hi, int v_lo, int v_hi,
+                                                                const int8_t *__restrict__ tmask, const FT *__restrict__ sic,
+                                                                double rmin_conc, int8_t *__restrict__ kill, uint8_t *__restrict__ kill9)
+{
+    const int lane = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6);
+    const int jr0 = j_lo + ((int)blockIdx.y * 4 + wv) * kSvRowsR;            // first output row of this wave
+    if (jr0 >= j_hi) return;                                                  // (wave-uniform: no barrier in this kernel)
+    const int g0 = (int)blockIdx.x * kSvRowsCols + 4 * (lane - 1);           // first of the lane's four columns (lane 0: halo left)
+    const bool in_cols = g0 >= 0 && g0 < Ni;                                  // Ni % 4 == 0: a group is inside the mesh or outside, whole
+    const bool out_lane = lane >= 1 && lane <= 62 && in_cols;
+    // columns of the domain rim (iT <= 1 or iT >= Ni-2, tracking.py:73), one bit per column of the group
+    unsigned rimc = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) rimc |= ((g0 + q <= 1 || g0 + q >= Ni - 2) ? 1u : 0u) << q;
+    // interior columns for the packed byte (1 <= i <= Ni-2)
+    unsigned intc = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) intc |= ((g0 + q >= 1 && g0 + q <= Ni - 2) ? 1u : 0u) << q;
+
+    const int r_first = jr0 - 2, r_last = min(jr0 + kSvRowsR, j_hi) + 1;     // rows to load: two above the first output row .. two below the last
+    Row4<FT> ring_s[kSvRowsD];
+    unsigned ring_t[kSvRowsD];
+    // (always a load, from a clamped address: a load inside a branch makes the compiler wait for ALL outstanding loads at every
+    // use -- `s_waitcnt vmcnt(0)` -- i.e. one row in flight instead of kSvRowsD; rows and columns outside the mesh read row 0 /
+    // column group 0 and are never used: such cells are rim or beyond)
+    const int gload = in_cols ? g0 : 0;
+    auto fetch = [&](int r, Row4<FT> &sv, unsigned &tv) {
+        const int rr = min(max(r, 0), min(Nj - 1, r_last));
+        const size_t k = (size_t)rr * Ni + gload;
+        sv = sv_load4<FT>(sic + k);
+        tv = *(const unsigned *)(tmask + k);
+    };
+#pragma unroll
+    for (int d = 0; d < kSvRowsD; d++) fetch(r_first + d, ring_s[d], ring_t[d]);
+
+    // rolling state: inputs of rows r-1 (S1, T1 with their edge neighbours) and r-2 (shifted: column q-1), Survive nibbles of rows r-3, r-2
+    Row4<FT> S1 = {(FT)0, (FT)0, (FT)0, (FT)0};
+    FT S1up = (FT)0, S1dn = (FT)0;
+    FT S0m1 = (FT)0, S0x = (FT)0, S0y = (FT)0, S0z = (FT)0;                  // row r-2 at columns q-1 for q = 0..3
+    unsigned T1 = 0, T1up = 0, T1dn = 0, T0sh = 0;                           // T0sh: row r-2's bytes at columns q-1 (4 bytes)
+    unsigned K0 = 0, K1 = 0;                                                 // 6-bit windows (columns -1..4) of the Survive bits of rows r-3, r-2
+
+    for (int it = 0; it < kSvRowsR + 4; it += kSvRowsD) {
+#pragma unroll
+        for (int d = 0; d < kSvRowsD; d++) {
+            const int r = r_first + it + d;                                   // the row that arrives now
+            const Row4<FT> S2 = ring_s[d];
+            const unsigned T2 = ring_t[d];
+            fetch(r + kSvRowsD, ring_s[d], ring_t[d]);                        // keep kSvRowsD rows in flight
+            // ---- Survive bytes of row jm = r-1 (tracking.py:62-93), four columns
+            const int jm = r - 1;
+            const bool rimrow = (jm <= 1) | (jm >= Nj - 2);
+            unsigned kn = 0;                                                  // nibble: bit q = kill(jm, g0+q)
+            {
+                const FT c1[6] = {S1up, S1.x, S1.y, S1.z, S1.w, S1dn};        // row jm, columns -1..4
+                const FT c0[4] = {S0m1, S0x, S0y, S0z};                       // row jm-1, columns q-1
+                const FT c2[4] = {S2.x, S2.y, S2.z, S2.w};                    // row jm+1, columns q
+                const unsigned long long w1 = ((unsigned long long)(T1up >> 24)) | ((unsigned long long)T1 << 8) | ((unsigned long long)(T1dn & 0xffu) << 40);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    // land-sea mask, 5 points; note [j-1,i-1] (:79): m[j,i] + m[j,i+1] + m[j+1,i] + m[j,i-1] + m[j-1,i-1]
+                    const int zmt = (int)(int8_t)(w1 >> (8 * (q + 1))) + (int)(int8_t)(w1 >> (8 * (q + 2))) + (int)(int8_t)(T2 >> (8 * q)) +
+                                    (int)(int8_t)(w1 >> (8 * q)) + (int)(int8_t)(T0sh >> (8 * q));
+                    // sea-ice concentration, same stencil, summed left to right in fp64 (:87-89)
+                    const double zic = 0.2 * ((double)c1[q + 1] + (double)c1[q + 2] + (double)c2[q] + (double)c1[q] + (double)c0[q]);
+                    const bool kl = rimrow | (((rimc >> q) & 1u) != 0) | (zmt < 5) | (zic < rmin_conc);
+                    kn |= (kl ? 1u : 0u) << q;
+                }
+            }
+            // the row's 6-bit window: neighbours' edge bits on both sides
+            const unsigned kup = (unsigned)sv_up1((int)kn), kdn = (unsigned)sv_dn1((int)kn);
+            const unsigned K2 = ((kup >> 3) & 1u) | (kn << 1) | ((kdn & 1u) << 5);
+            // ---- outputs of row jo = r-2
+            const int jo = r - 2;
+            if (jo >= jr0 && jo < j_hi && jo < jr0 + kSvRowsR && out_lane) {   // (row conditions are wave-uniform)
+                bool ok3 = (jo >= 1) & (jo <= Nj - 2);
+#pragma unroll
+                for (int dj = -1; dj <= 1; dj++) {
+                    const int rr = jo + dj;
+                    ok3 = ok3 & ((rr <= 1) | (rr >= Nj - 2) | ((rr - 1 >= v_lo) & (rr + 1 < v_hi)));
+                }
+                const bool wr_kill = (jo <= 1) | (jo >= Nj - 2) | ((jo - 1 >= v_lo) & (jo + 1 < v_hi));
+                unsigned w9 = 0, wk = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    unsigned w = ((K0 >> q) & 7u) | (((K1 >> q) & 1u) << 3) | (((K1 >> (q + 2)) & 1u) << 4) | (((K2 >> q) & 7u) << 5);
+                    if (!(ok3 && ((intc >> q) & 1u))) w = 0xffu;
+                    w9 |= w << (8 * q);
+                    wk |= ((K1 >> (q + 1)) & 1u) << (8 * q);
+                }
+                const size_t k = (size_t)jo * Ni + g0;
+                if (wr_kill) *(unsigned *)(kill + k) = wk;
+                *(unsigned *)(kill9 + k) = w9;
+            }
+            // ---- roll: row r becomes row r-1
+            S0m1 = S1up; S0x = S1.x; S0y = S1.y; S0z = S1.z;
+            T0sh = (T1 << 8) | (T1up >> 24);
+            S1 = S2; T1 = T2;
+            S1up = sv_shfl_up(S2.w); S1dn = sv_shfl_dn(S2.x);
+            T1up = (unsigned)sv_up1((int)T2); T1dn = (unsigned)sv_dn1((int)T2);
+            K0 = K1; K1 = K2;
+        }
+    }
+}
+
 // rows of the host cells of the buoys that are still alive: out[0] = min jT, out[1] = max jT
 __global__ __launch_bounds__(kBlock) void buoy_rows_kernel(int64_t n, const int32_t *__restrict__ cell, int *out)
 {

@@ -60,7 +60,7 @@ def one_case(rng, idx, nstrat=2):
     trk.ctx.set_tuning(fuse=fuse, sort_tile=tile, nt_state=int(rng.integers(0, 2)), xcd_remap=int(rng.integers(0, 2)),
                        step_block=int(rng.choice([256, 512, 1024])),
                        patch_kb=int(rng.choice([0, 2, 16, 40])), patch_margin=int(rng.choice([0, 2, 8])),
-                       xcd_group=int(rng.choice([0, 3, 16])))
+                       xcd_group=int(rng.choice([0, 3, 16])), survive_tile=int(rng.integers(0, 2)))
     trk.set_buoys(yx, ji, first, last, sort=bool(rng.random() < 0.8))
     trk.ctx.set_resort(int(rng.choice([0, 3, 17])))
     g2 = dict(grid); g2["tmask"] = tmask

@@ -62,6 +62,78 @@ def test_g4_survive_on_device(golden, ctx):
         assert np.array_equal(mask.ravel(), g[key].astype(np.int8)), key     # jiT in G4 enumerates the grid in C order
 
 
+@pytest.mark.parametrize("shape", [(37, 44), (70, 252), (66, 500), (40, 46)])
+def test_survive_kernels_agree_with_the_oracle_on_every_cell(ctx, shape):
+    """`Survive` for every cell through both device forms -- the register-rolling kernel (meshes with Ni % 4 == 0: a wave walks
+    down a strip of 248 columns, so 252 and 500 columns cross strip boundaries; more rows than one 32-row chunk) and the LDS-tile
+    kernel (any Ni; forced by the knob `survive_tile`) -- against the oracle's scalar `Survive` (tracking.py:62-93): land
+    stencils incl. the asymmetric [j-1,i-1] point and mask values other than 0/1, ice around the threshold, NaN and huge ice."""
+    Nj, Ni = shape
+    rng = np.random.default_rng(Nj * 1000 + Ni)
+    tmask = (rng.random((Nj, Ni)) > 0.08).astype(np.int8)
+    tmask[rng.integers(2, Nj - 2, 6), rng.integers(2, Ni - 2, 6)] = 2          # a 5-point sum can reach 5 with a land point in it
+    tmask[rng.integers(2, Nj - 2, 6), rng.integers(2, Ni - 2, 6)] = -1
+    sic = rng.choice([0.0, 0.05, 0.0999, 0.1, 0.1001, 0.12, 0.5, 1.0], size=(Nj, Ni)).astype(np.float64)
+    sic[rng.integers(0, Nj, 8), rng.integers(0, Ni, 8)] = np.nan
+    sic[rng.integers(0, Nj, 4), rng.integers(0, Ni, 4)] = 1e20
+    z = np.zeros((Nj, Ni))
+    ctx.set_grid(z, z, z, z, z, z, tmask)
+    ctx.set_params(3600., 1, 0.1)
+    want = np.array([[orc.Survive((j, i), tmask, sic) for i in range(Ni)] for j in range(Nj)], dtype=np.int8)
+    assert 0.2 < want[2:-2, 2:-2].mean() < 0.9
+    got = {}
+    for tile in (0, 1):
+        ctx.set_tuning(survive_tile=tile)
+        got[tile] = ctx.survive_mask(sic)
+    ctx.set_tuning(survive_tile=0)
+    assert np.array_equal(got[1], want), "LDS-tile kernel"
+    assert np.array_equal(got[0], want), "register-rolling kernel" if Ni % 4 == 0 else "LDS-tile kernel (Ni % 4 != 0)"
+
+
+@pytest.mark.parametrize("fdt", [np.float32, np.float64])
+def test_survive_bytes_of_resident_records_both_kernels(fdt):
+    """The Survive bytes AND the packed 8-neighbour bytes of resident records, as the trajectories see them: a fast flow over a
+    500-column mesh (two strip boundaries of the register-rolling kernel), holes in the ice and land -- one-record launches read
+    the bytes, fused launches the packed neighbourhoods; both kernels, float32 and float64 records, against the oracle."""
+    Nj, Ni, K, Nt = 70, 500, 4, 24
+    grid = syn.make_grid(Nj, Ni, dkm=4.0, warp=1.0)
+    u, v, sic = syn.make_fields(grid, K=K, seed=5, umax=1.0, drift=0.6, ripple=0.1, dtype=fdt)
+    rng = np.random.default_rng(3)
+    tmask = grid["tmask"].copy()
+    for _ in range(40):
+        j, i = int(rng.integers(3, Nj - 4)), int(rng.integers(3, Ni - 4))
+        tmask[j, i] = 0
+    for k in range(K):
+        for _ in range(30):
+            j, i = int(rng.integers(3, Nj - 6)), int(rng.integers(3, Ni - 8))
+            sic[k, j:j + 2, i:i + 3] = 0.04
+    _, yx = syn.make_buoys(grid, 40000, seed=8, frac=0.92)
+    g2 = dict(grid); g2["tmask"] = tmask
+    res = {}
+    for tile in (0, 1):
+        for mode in ("run", "step"):
+            trk = sit.IceTracker(grid["Yf"], grid["Xf"], grid["Yu"], grid["Xu"], grid["Yv"], grid["Xv"], tmask, nslots=K, field_dtype=fdt)
+            trk.ctx.set_tuning(survive_tile=tile)
+            found, ji, _ = sit.FindContainingCell(yx, syn.nearest_t_plane(grid, yx), ctx=trk.ctx)
+            p, c = yx[found], ji[found]
+            trk.set_buoys(p, c)
+            for k in range(K):
+                trk.load_record(k, u[k], v[k], sic[k])
+            if mode == "run":
+                trk.ctx.run(0, 0, Nt)
+            else:
+                for s_ in range(Nt):
+                    trk.step(s_, s_ % K)
+            res[(tile, mode)] = trk.state()
+            trk.close()
+    ref = orc.Tracker(g2, p, c, nthreads=8)
+    for s_ in range(Nt):
+        ref.step(s_, u[s_ % K].astype(np.float64), v[s_ % K].astype(np.float64), sic[s_ % K].astype(np.float64), want_out=False)
+    assert 0.02 < (ref.alive == 0).mean() < 0.9
+    for key, st in res.items():
+        assert np.array_equal(st["yx"], ref.pos) and np.array_equal(st["vJIt"], ref.jiT) and np.array_equal(st["iAlive"], ref.alive), key
+
+
 @pytest.mark.parametrize("tag", ["curvi", "regular"])
 @pytest.mark.parametrize("strat", [1, 0])
 @pytest.mark.parametrize("sort", [True, False])
@@ -628,7 +700,7 @@ def test_tuning_knobs_do_not_change_results():
                   {"sort_tile": 5 * 256 + 7, "nt_state": 1, "xcd_remap": 1},
                   # the fused kernel's LDS patch: none, tiny (most buoys leave it: global fallback), large; XCD grouping; one-record launches
                   {"patch_kb": 0}, {"patch_kb": 1, "patch_margin": 0}, {"patch_kb": 60, "patch_margin": 40}, {"xcd_group": 0},
-                  {"xcd_group": 5, "patch_kb": 3}, {"fuse": 1}, {"fuse": 2, "patch_kb": 2}):
+                  {"xcd_group": 5, "patch_kb": 3}, {"fuse": 1}, {"fuse": 2, "patch_kb": 2}, {"survive_tile": 1}):
         trk = make_tracker(grid, grid["tmask"], 3)
         found, ji, _ = sit.FindContainingCell(yx, syn.nearest_t_plane(grid, yx), ctx=trk.ctx)
         trk.ctx.set_tuning(**knobs)
