@@ -133,6 +133,7 @@ SITRK_API int sitrk_destroy(sitrk_t *h)
     free_buoys(h);
     free_records(h);
     dev_free(h->geo); dev_free(h->geoF); dev_free(h->orient); dev_free(h->tmask); dev_free(h->scratch); dev_free(h->counter);
+    dev_free(h->stamps);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     for (int b = 0; b < sitrk_ctx::kStage; b++) if (h->stage_done[b]) (void)hipEventDestroy(h->stage_done[b]);
@@ -260,6 +261,7 @@ SITRK_API int sitrk_set_tuning(sitrk_t *h, const char *knob, int value)
     }
     else if (!strcmp(knob, "locate_bruteforce")) bit = TUNE_LOCATE_BRUTEFORCE;
 #ifdef SITRK_DIAG
+    else if (!strcmp(knob, "stamps")) { h->stamps_on = value != 0; return SITRK_OK; }
     else if (!strcmp(knob, "diag_memonly")) bit = TUNE_DIAG_MEMONLY;
     else if (!strcmp(knob, "diag_nocross")) bit = TUNE_DIAG_NOCROSS;
 #endif
@@ -860,6 +862,19 @@ SITRK_API int sitrk_run(sitrk_t *h, int slot0, int jrec0, int nsteps)
         ra.patch_margin = h->patch_margin;
         ra.xcd_group = h->xcd_group;
         ra.f32_class = f32_class_for(h->rdt);
+#ifdef SITRK_DIAG
+        ra.stamps = nullptr;
+        if (h->stamps_on) {
+            const size_t nw = (size_t)nblocks(h->nP, kRunBlock) * (kRunBlock / 64);
+            if (nw > h->stamps_waves) {
+                dev_free(h->stamps); h->stamps = nullptr; h->stamps_waves = 0;
+                HIPCHK(hipMalloc((void **)&h->stamps, nw * 8 * sizeof(unsigned long long)));
+                h->stamps_waves = nw;
+            }
+            HIPCHK(hipMemsetAsync(h->stamps, 0, h->stamps_waves * 8 * sizeof(unsigned long long), h->stream));
+            ra.stamps = h->stamps;
+        }
+#endif
         int used[kMaxFuse];
         for (int r = 0; r < m; r++) {
             const int slot = (slot0 + k + r) % h->nslots;
@@ -888,6 +903,20 @@ SITRK_API int sitrk_run(sitrk_t *h, int slot0, int jrec0, int nsteps)
     }
     return SITRK_OK;
 }
+
+#ifdef SITRK_DIAG
+// diagnostic builds only (not in include/sitrk.h): the s_memtime intervals of the last fused launch, 8 per wave
+SITRK_API int sitrk_diag_stamps(sitrk_t *h, unsigned long long *out, long long max_waves, long long *nwaves)
+{
+    NEED(h, "null handle");
+    NEED(out && nwaves, "sitrk_diag_stamps: null output");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const long long n = std::min<long long>((long long)h->stamps_waves, max_waves);
+    *nwaves = n;
+    if (n > 0) HIPCHK(hipMemcpy(out, h->stamps, (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return SITRK_OK;
+}
+#endif
 
 SITRK_API int sitrk_launch_stats(sitrk_t *h, int reset, int64_t *fused_launches, int64_t *fused_records, int64_t *step_launches)
 {

@@ -106,6 +106,11 @@ struct sitrk_ctx {
     int steps_since_sort = 0;
     bool sorted_once = false;
 
+    // diagnostic builds (make DIAG=1, knob "stamps"): per-wave s_memtime intervals of the fused loop's last launch
+    unsigned long long *stamps = nullptr;
+    size_t stamps_waves = 0;
+    bool stamps_on = false;
+
     // scratch for fetch / locate
     void *scratch = nullptr;
     size_t scratch_bytes = 0;

@@ -690,6 +690,9 @@ struct RunArgs {
     int dji[4][7][2];                   // its (dj,di) pairs: va, vb, eA, eB, S, A, B per crossed edge (for the patch's own offsets)
     int patch_cells, patch_margin;      // LDS patch: capacity in cells (0 = no patch) and the largest margin to try
     int xcd_group;                      // > 1: runs of that many consecutive workgroups share an XCD
+#ifdef SITRK_DIAG
+    unsigned long long *stamps;         // diagnostic builds: per wave 8 accumulated s_memtime intervals of the record loop (or null)
+#endif
     int f32_class;                      // v_cmp_class mask of div1000_of_f32: finite and non-zero, or 0 when |rdt| is outside
                                         // [2^-700, 2^700] (every lane then divides)
 };
@@ -823,6 +826,20 @@ static constexpr int kRunBlock = SITRK_RUN_BLOCK;
 #define SITRK_RUN_WAVES_WINDOW 6        // the form with per-buoy record windows carries two more registers: 9 spilled at 7 waves (13-25
                                         // with the window packed into one register, as a single test, or as a predicate on the body)
 #endif
+// In-kernel stamps (diagnostic builds, `make DIAG=1`, knob "stamps"): where ONE wave's time goes inside a record.  s_memtime ticks
+// are shader cycles; the values go to a buffer nothing else reads.  SITRK_STAMP(k) closes interval k.
+#ifdef SITRK_DIAG
+#define SITRK_STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = 0; const bool st_on = ra.stamps != nullptr;
+#define SITRK_STAMP_START if (st_on) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t) :: "memory"); }
+#define SITRK_STAMP(k) if (st_on) { unsigned long long st_n; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_n) :: "memory"); st_acc[k] += st_n - st_t; st_t = st_n; }
+#define SITRK_STAMP_FLUSH(widx) if (st_on && (threadIdx.x & 63u) == 0) { for (int q_ = 0; q_ < 8; q_++) ra.stamps[(size_t)(widx) * 8 + q_] = st_acc[q_]; }
+#else
+#define SITRK_STAMP_DECL
+#define SITRK_STAMP_START
+#define SITRK_STAMP(k)
+#define SITRK_STAMP_FLUSH(widx)
+#endif
+
 template <typename FT, int UVS, bool WINDOW>
 __global__ __launch_bounds__(kRunBlock, WINDOW ? SITRK_RUN_WAVES_WINDOW : SITRK_RUN_WAVES) void advect_run_kernel(RunArgs ra)
 {
@@ -909,9 +926,11 @@ __global__ __launch_bounds__(kRunBlock, WINDOW ? SITRK_RUN_WAVES_WINDOW : SITRK_
     const char *ub_next = (const char *)ra.u[0], *vb_next = (const char *)ra.v[0], *kb_next = (const char *)ra.kill9[0];
     double k1000 = 1000.;                                // div1000's constant, kept in scalar registers
     asm volatile("" : "+s"(k1000));
+    SITRK_STAMP_DECL
 #pragma unroll 1
     for (int r = 0; r < ra.nrec; r++) {
         const int jrec = a.jrec + r;
+        SITRK_STAMP_START
         const char *ub = ub_next, *vb = vb_next, *kb = kb_next;
         const int rn = (r + 1 < ra.nrec) ? r + 1 : r;
         ub_next = (const char *)ra.u[rn]; vb_next = (const char *)ra.v[rn]; kb_next = (const char *)ra.kill9[rn];
@@ -935,10 +954,22 @@ __global__ __launch_bounds__(kRunBlock, WINDOW ? SITRK_RUN_WAVES_WINDOW : SITRK_
         } else {                                         // :427-441
             // all four candidates are requested up front (pin_load: none is sunk into the branch that selects it)
             // intersect2Seg(P,F,C,D) = (ccw(P,C,D) != ccw(F,C,D)) and (ccw(P,F,C) != ccw(P,F,D)); ccw(F,C,D) is per cell
+#ifdef SITRK_DIAG
+            if (st_on) { pin_load(x.ori); pin_load(x.U11.y); pin_load(x.V11.y); pin_load(x.U10.y); pin_load(x.V01.y); pin_load(x.F11.y); pin_load(x.F00.y); }
+            SITRK_STAMP(0)                               // the cell's context is there (requested by the previous record's crossing path)
+#endif
             const bool sFV = (x.ori & 1u) != 0, sFU = (x.ori & 2u) != 0;
             const bool llum1 = (ccw(P, x.V01, x.V11) != sFV) && (ccw(P, x.F11, x.V01) != ccw(P, x.F11, x.V11));
             const bool llvm1 = (ccw(P, x.U10, x.U11) != sFU) && (ccw(P, x.F11, x.U10) != ccw(P, x.F11, x.U11));
+#ifdef SITRK_DIAG
+            if (st_on) { int b_ = (llum1 ? 1 : 0) | (llvm1 ? 2 : 0); asm volatile("" : "+v"(b_)); }
+            SITRK_STAMP(1)                               // the pick's orientation tests
+#endif
             pin_load(fu0); pin_load(fv0);
+#ifdef SITRK_DIAG
+            if (st_on) { pin_load(fu1); pin_load(fv1); }
+            SITRK_STAMP(2)                               // the record's velocities are there
+#endif
             su = llum1 ? fu0 : fu1;
             sv = llvm1 ? fv0 : fv1;
             zU = (double)su;
@@ -959,7 +990,16 @@ __global__ __launch_bounds__(kRunBlock, WINDOW ? SITRK_RUN_WAVES_WINDOW : SITRK_
         }
         moved = true;
         bool killed = false;
-        if (!SITRK_INSIDE(Pn.y, Pn.x, x.F00, x.F01, x.F11, x.F10, a.eps_mg)) {      // :466-484
+#ifdef SITRK_DIAG
+        if (st_on) { pin_load(Pn.x); pin_load(Pn.y); }
+        SITRK_STAMP(3)                                   // Euler update
+#endif
+        const bool still_in = SITRK_INSIDE(Pn.y, Pn.x, x.F00, x.F01, x.F11, x.F10, a.eps_mg);
+#ifdef SITRK_DIAG
+        if (st_on) { int b_ = still_in ? 1 : 0; asm volatile("" : "+v"(b_)); }
+        SITRK_STAMP(4)                                   // cell test
+#endif
+        if (!still_in) {      // :466-484
             const unsigned kcell = x.o1 / (unsigned)sizeof(FT);
             int dcell, dk, dlo = 0;
             pin_load(k9);
@@ -983,6 +1023,10 @@ __global__ __launch_bounds__(kRunBlock, WINDOW ? SITRK_RUN_WAVES_WINDOW : SITRK_
             else load_ctx<sizeof(FT)>(a, gb, kcell + (unsigned)dk, x);
         }
         P = Pn;
+#ifdef SITRK_DIAG
+        if (st_on) { int b_ = c; asm volatile("" : "+v"(b_)); }
+        SITRK_STAMP(5)                                   // crossing path (resolution; the new context is requested, not waited for)
+#endif
         if (killed) {
             c |= SITRK_DEAD_BIT;
             unsigned tk = threadIdx.x;
@@ -991,6 +1035,7 @@ __global__ __launch_bounds__(kRunBlock, WINDOW ? SITRK_RUN_WAVES_WINDOW : SITRK_
             break;                                       // dead buoys never step again
         }
     }
+    SITRK_STAMP_FLUSH((size_t)blk * (kRunBlock / 64) + (threadIdx.x >> 6))
     // (the buoy's index is recomputed here rather than kept: 16 bytes of state addresses per lane would be spilled to
     // scratch across the loop, i.e. written and read back through HBM)
     unsigned tid = threadIdx.x;
