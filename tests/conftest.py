@@ -23,3 +23,31 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+def g5c_mesh(g):
+    """Golden set G5c stores its seeds and the reference's outputs only; its 300 x 330 mesh is rebuilt here from the stored
+    parameters exactly as tests/golden/gen_golden.py::polar_grid built it (synthetic grid + the oracle's inverse projection
+    for the T-points' lat/lon) and checked against the stored checksums and probes before it is used."""
+    from oracle import oracle as orc
+    from sitrack_amd import synthetic as syn
+    Nj, Ni, dkm, warp, yc, xc = g["mesh"]
+    Nj, Ni = int(Nj), int(Ni)
+    m = syn.make_grid(Nj, Ni, dkm=float(dkm), warp=float(warp))
+    for k in ("Yt", "Yu", "Yv", "Yf"):
+        m[k] = m[k] + float(yc)
+    for k in ("Xt", "Xu", "Xv", "Xf"):
+        m[k] = m[k] + float(xc)
+    ll = orc.CartNPSkm2Geo1D(np.stack([m["Yt"].ravel(), m["Xt"].ravel()], axis=1))
+    m["latT"] = np.ascontiguousarray(ll[:, 0].reshape(Nj, Ni))
+    m["lonT"] = np.ascontiguousarray(np.mod(ll[:, 1], 360.).reshape(Nj, Ni))
+    assert np.array_equal(m["latT"][::37, ::41], g["lat_probe"]) and np.array_equal(m["lonT"][::37, ::41], g["lon_probe"]), \
+        "the rebuilt G5c mesh differs from the one the golden outputs were generated on"
+    assert m["latT"].sum() == float(g["lat_sum"]) and m["lonT"].sum() == float(g["lon_sum"])
+    tmask = m["tmask"].copy()
+    for j0, j1, i0, i1 in g["tmask_boxes"]:
+        tmask[j0:j1, i0:i1] = 0
+    sic = np.ones((Nj, Ni))
+    for (j0, j1, i0, i1), v in zip(g["sic_boxes"], g["sic_vals"]):
+        sic[j0:j1, i0:i1] = v
+    return m, tmask, sic

@@ -312,6 +312,48 @@ def g5b_seedinit_on_points():
     save("g5b_seeds_on_points.npz", **out)
 
 
+# --------------------------------------------------------------------------- G5c
+def g5c_seedinit_larger_mesh():
+    """`SeedInit` / `NearestPoint` of the reference on a mesh large enough for the device search's bounding-sphere hierarchy
+    (16 x 16-point blocks, 16 x 16-block superblocks): 300 x 330 T-points around the pole (the pole is INSIDE the mesh: longitudes
+    wrap through 0/360 and every meridian is present), 2 600 seeds -- random inside and around the mesh, exactly on T-points, near
+    F-points, far outside.  Only the seeds and the reference's outputs are stored; the mesh is rebuilt by the test from its
+    parameters with the same code (`polar_grid`, deterministic) and guarded by checksums of its lat/lon arrays."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(1242)
+    Nj, Ni, dkm, warp, yc, xc = 300, 330, 6.0, 1.0, 40., -25.
+    g = polar_grid(Nj, Ni, dkm, warp=warp, yc=yc, xc=xc)
+    tmask = g["tmask"].copy(); tmask[100:130, 200:260] = 0; tmask[10:14, 10:60] = 0
+    sic = np.ones((Nj, Ni)); sic[200:240, 40:120] = 0.02; sic[150:155, 150:300] = 0.0999
+    ylo, yhi = g["Yt"].min(), g["Yt"].max(); xlo, xhi = g["Xt"].min(), g["Xt"].max()
+    yx = [np.stack([rng.uniform(ylo - 40, yhi + 40, 1800), rng.uniform(xlo - 40, xhi + 40, 1800)], axis=1)]
+    jj, ii = rng.integers(0, Nj, 350), rng.integers(0, Ni, 350)
+    yx.append(np.stack([g["Yt"][jj, ii], g["Xt"][jj, ii]], axis=1))
+    jj, ii = rng.integers(2, Nj - 2, 350), rng.integers(2, Ni - 2, 350)
+    yx.append(np.stack([g["Yf"][jj, ii] + rng.normal(0, 0.2, 350), g["Xf"][jj, ii] + rng.normal(0, 0.2, 350)], axis=1))
+    yx.append(np.array([[yhi + 600., 0.], [0., xlo - 900.], [ylo - 3000., xhi + 3000.]] + [[0.001 * k, -0.002 * k] for k in range(97)]))   # far away; around the pole
+    yx = np.concatenate(yx)
+    nP = yx.shape[0]
+    ll = orc.CartNPSkm2Geo1D(yx)
+    pSG = np.stack([ll[:, 0].astype(np.float32).astype(np.float64), np.mod(ll[:, 1].astype(np.float32).astype(np.float64), 360.)], axis=1)
+    pSC = yx.astype(np.float32).astype(np.float64)
+    ids = (np.arange(nP) + 1).astype(np.int64) * 11
+    npj = np.empty((nP, 2), dtype=np.int64)
+    with quiet():
+        for k in range(nP):
+            npj[k] = locate.NearestPoint((pSG[k, 0], pSG[k, 1]), g["latT"], g["lonT"], rd_found_km=tracking.rFoundKM,
+                                         resolkm=g["resol"], max_itr=10)
+        out = tracking.SeedInit(ids.copy(), pSG.copy(), pSC.copy(), g["latT"], g["lonT"], g["Yf"], g["Xf"], g["resol"], tmask,
+                                xIceConc=sic, iverbose=0)
+    nPn, oSG, oSC, oIDs, ojiT, overt, okeep = out
+    print("   G5c: %d seeds -> %d kept; nearest-not-found %d" % (nP, nPn, (npj[:, 0] < 0).sum()))
+    save("g5c_seedinit_300x330.npz", mesh=np.array([Nj, Ni, dkm, warp, yc, xc]), lat_sum=np.float64(g["latT"].sum()),
+         lon_sum=np.float64(g["lonT"].sum()), lat_probe=g["latT"][::37, ::41].copy(), lon_probe=g["lonT"][::37, ::41].copy(),
+         tmask_boxes=np.array([[100, 130, 200, 260], [10, 14, 10, 60]]), sic_boxes=np.array([[200, 240, 40, 120], [150, 155, 150, 300]]),
+         sic_vals=np.array([0.02, 0.0999]), ids=ids, pSG=pSG, pSC=pSC, nearest=npj,
+         nPn=np.int64(nPn), oIDs=oIDs, ojiT=np.asarray(ojiT), okeep=okeep)
+
+
 # --------------------------------------------------------------------------- G6
 def reference_loop(g, tmask, u, v, sic, yx0, jiT0, vert0, rec_first, rec_last, kstrt, Nt, rdt, strategy):
     """Drives the reference predicates in the order of si3_part_tracker.py:361-496.
@@ -497,7 +539,7 @@ def g10_nemoseed():
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, fn in (("g1", g1_inside), ("g2", g2_intersect), ("g3", g3_crossing), ("g4", g4_survive),
-                     ("g5", g5_seedinit), ("g5b", g5b_seedinit_on_points), ("g6", g6_trajectories), ("g7", g7_projection), ("g8", g8_timespan),
+                     ("g5", g5_seedinit), ("g5b", g5b_seedinit_on_points), ("g5c", g5c_seedinit_larger_mesh), ("g6", g6_trajectories), ("g7", g7_projection), ("g8", g8_timespan),
                      ("g9", g9_haversine), ("g10", g10_nemoseed)):
         if not only or name in only:
             fn()

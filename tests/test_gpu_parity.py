@@ -782,6 +782,24 @@ def test_seed_init_on_t_and_f_points_matches_reference_golden(golden, ctx, mesh,
     assert np.allclose(dmin, P("dmin"), rtol=1e-12, atol=1e-9)
 
 
+@pytest.mark.parametrize("bruteforce", [0, 1])
+def test_seed_init_on_the_300x330_mesh_matches_reference_golden(golden, ctx, bruteforce):
+    """G5c through `sitrk_seed_init` / `sitrk_nearest_point`: REFERENCE output on a mesh large enough for the bounding-sphere
+    hierarchy (2 x 2 superblocks of 16 x 16 blocks of 16 x 16 points), with the pole inside the mesh; both locate modes."""
+    from conftest import g5c_mesh
+    g = golden("g5c_seedinit_300x330.npz")
+    m, tmask, sic = g5c_mesh(g)
+    ctx.set_grid(m["Yf"], m["Xf"], m["Yf"], m["Xf"], m["Yf"], m["Xf"], tmask)
+    ctx.set_tuning(locate_bruteforce=bruteforce)
+    try:
+        out = sit.SeedInit(g["ids"], g["pSG"], g["pSC"], m["latT"], m["lonT"], m["Yf"], m["Xf"], m["resol"], tmask, xIceConc=sic, ctx=ctx)
+        near, _ = ctx.nearest_point(g["pSG"], m["latT"], m["lonT"], resolkm=m["resol"], rd_found_km=2.5, max_itr=10)
+    finally:
+        ctx.set_tuning(locate_bruteforce=0)
+    assert out[0] == int(g["nPn"]) and np.array_equal(out[6], g["okeep"]) and np.array_equal(out[3], g["oIDs"]) and np.array_equal(out[4], g["ojiT"])
+    assert np.array_equal(near, g["nearest"])
+
+
 @pytest.mark.parametrize("yc,xc", [(-300., 200.), (0., 0.), (-2500., 1800.)])
 def test_seed_search_equals_whole_grid_scan(ctx, yc, xc):
     """Bounding-sphere search == exhaustive Haversine argmin, incl. seeds exactly on T- and F-points

@@ -140,6 +140,20 @@ def test_g5b_seeds_exactly_on_t_and_f_points(golden, mesh, prec):
         assert (P("gap") == 0).sum() > 500                                # the exact ties are really in the set
 
 
+def test_g5c_seedinit_on_a_300x330_mesh_around_the_pole(golden):
+    """G5c: the reference's SeedInit on a mesh of 99 000 T-points with the pole inside it (2 600 seeds).  The oracle's scalar
+    whole-grid scan must give the reference's nearest points (every 9th seed here: 1e5 Haversines each), kept set and cells."""
+    from conftest import g5c_mesh
+    g = golden("g5c_seedinit_300x330.npz")
+    m, tmask, sic = g5c_mesh(g)
+    for k in range(0, len(g["ids"]), 9):
+        jy, jx = orc.NearestPoint(g["pSG"][k], m["latT"], m["lonT"], rd_found_km=orc.rFoundKM, resolkm=m["resol"], max_itr=10)
+        assert (jy, jx) == tuple(g["nearest"][k]), k
+    nPn, oSG, oSC, oIDs, ojiT, overt, okeep = orc.SeedInit(g["ids"], g["pSG"], g["pSC"], m["latT"], m["lonT"], m["Yf"], m["Xf"],
+                                                           m["resol"], tmask, sic, nthreads=8)
+    assert nPn == int(g["nPn"]) and np.array_equal(okeep, g["okeep"]) and np.array_equal(oIDs, g["oIDs"]) and np.array_equal(ojiT, g["ojiT"])
+
+
 @pytest.mark.parametrize("tag", ["curvi", "regular"])
 @pytest.mark.parametrize("strat", [1, 0])
 def test_g6_trajectories_bit_exact(golden, tag, strat):
