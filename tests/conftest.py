@@ -51,3 +51,30 @@ def g5c_mesh(g):
     for (j0, j1, i0, i1), v in zip(g["sic_boxes"], g["sic_vals"]):
         sic[j0:j1, i0:i1] = v
     return m, tmask, sic
+
+
+def g6b_case(g):
+    """Golden set G6b (fast flow, 120 x 140 warped grid): grid and fields rebuilt from the stored parameters, guarded by checksums."""
+    from sitrack_amd import synthetic as syn
+    Nj, Ni, dkm, warp = g["mesh"]
+    K, seed, umax, drift, ripple = g["fields"]
+    grid = syn.make_grid(int(Nj), int(Ni), dkm=float(dkm), warp=float(warp))
+    u, v, sic = syn.make_fields(grid, K=int(K), seed=int(seed), umax=float(umax), drift=float(drift), ripple=float(ripple))
+    tmask = grid["tmask"].copy()
+    for j0, j1, i0, i1 in g["tmask_boxes"]:
+        tmask[j0:j1, i0:i1] = 0
+    sic = sic.copy()
+    for k in range(int(K)):
+        sic[k, 20:30, 90 + 2 * k:105 + 2 * k] = 0.03
+    assert u.astype(np.float64).sum() == float(g["u_sum"]) and sic.astype(np.float64).sum() == float(g["sic_sum"]), \
+        "the rebuilt G6b fields differ from the ones the golden outputs were generated on"
+    grid["tmask"] = tmask
+    return grid, u, v, sic
+
+
+def traj_digest_row(pos, msk, jit, alive):
+    """one record's digest as tests/golden/gen_golden.py::traj_digest forms it"""
+    m = msk == 1
+    bits = np.ascontiguousarray(pos[m]).reshape(-1).view(np.uint64)
+    return np.array([np.bitwise_xor.reduce(bits) if bits.size else 0, int(m.sum()),
+                     int((jit.astype(np.int64) * np.array([100003, 1])).sum() % (1 << 62)), int((alive == 1).sum())], dtype=np.uint64)

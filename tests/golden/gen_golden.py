@@ -470,6 +470,71 @@ def g6_trajectories():
              rec_first=rec_first, rec_last=rec_last, kstrt=np.int64(kstrt), Nt=np.int64(Nt), rdt=np.float64(rdt), **out)
 
 
+def traj_digest(pos, msk, jit, alive):
+    """per-record digests of a trajectory set: XOR of the bit patterns of the positions of the buoys that stepped, their
+    number, a checksum of the host cells, the number alive -- bit-exact comparison without storing (Nt, nP, 2) arrays"""
+    Nt1 = pos.shape[0]
+    dg = np.zeros((Nt1, 4), dtype=np.uint64)
+    for k in range(Nt1):
+        m = msk[k] == 1
+        bits = pos[k][m].reshape(-1).view(np.uint64)
+        dg[k, 0] = np.bitwise_xor.reduce(bits) if bits.size else 0
+        dg[k, 1] = int(m.sum())
+        dg[k, 2] = int((jit[k].astype(np.int64) * np.array([100003, 1])).sum() % (1 << 62))
+        dg[k, 3] = int((alive[k] == 1).sum())
+    return dg
+
+
+def g6b_fast_flow_trajectories():
+    """A larger trajectory set from the restated reference loop: 120 x 140 warped grid, 1 500 buoys, 90 records of a FAST flow
+    (up to two cells per record: `CrossedEdge` falls through to 4 and `NewHostCell` puts buoys into cells that do not contain
+    them -- the reference's own behaviour, which the build must reproduce), islands, drifting open water, both velocity rules.
+    Stored: the initial state, the final state and per-record digests (traj_digest); grid and fields are rebuilt by the test
+    from their parameters with sitrack_amd.synthetic and guarded by checksums."""
+    Nj, Ni, dkm, warp = 120, 140, 4.0, 1.0
+    nP, Nt, K, kstrt, rdt = 1500, 90, 6, 2, 3600.
+    g = syn.make_grid(Nj, Ni, dkm=dkm, warp=warp)
+    u, v, sic = syn.make_fields(g, K=K, seed=777, umax=2.2, drift=0.6, ripple=0.2)
+    tmask = g["tmask"].copy()
+    tmask[40:46, 60:70] = 0; tmask[80:83, 20:50] = 0
+    sic = sic.copy()
+    for k in range(K):
+        sic[k, 20:30, 90 + 2 * k:105 + 2 * k] = 0.03
+    _, cand = syn.make_buoys(g, 2 * nP, seed=4321, frac=0.8)
+    yx0 = np.zeros((nP, 2)); jiT0 = np.zeros((nP, 2), dtype=np.int64); vert0 = np.zeros((nP, 2, 4), dtype=np.int64)
+    b = 0
+    for c in cand:
+        d2 = (g["Yt"] - c[0]) ** 2 + (g["Xt"] - c[1]) ** 2
+        gj, gi = np.unravel_index(np.argmin(d2), d2.shape)
+        if not (2 <= gj < Nj - 2 and 2 <= gi < Ni - 2):
+            continue
+        ok, ji, vv = locate.FindContainingCell((c[0], c[1]), (gj, gi), g["Yf"], g["Xf"])
+        if ok and b < nP and tmask[ji[0], ji[1]] == 1:
+            yx0[b] = c; jiT0[b] = ji; vert0[b] = np.array(vv); b += 1
+    assert b == nP, b
+    rec_first = np.full(nP, kstrt, dtype=np.int64); rec_last = np.full(nP, kstrt + Nt - 1, dtype=np.int64)
+    out = {}
+    for strat in (1, 0):
+        with quiet():
+            pos, msk, jit_rec, alive_rec, vert, codes = reference_loop(
+                g, tmask, u.astype(np.float64), v.astype(np.float64), sic.astype(np.float64),
+                yx0, jiT0, vert0, rec_first, rec_last, kstrt, Nt, rdt, strat)
+        print("   G6b strat %d: crossings by code %s  dead %d/%d" % (strat, codes[1:].tolist(), int((alive_rec[-1] == 0).sum()), nP))
+        last = np.full((nP, 2), FILL)
+        for k in range(Nt + 1):
+            m = msk[k] == 1
+            last[m] = pos[k][m]
+        out["digest_s%d" % strat] = traj_digest(pos, msk, jit_rec, alive_rec)
+        out["last_pos_s%d" % strat] = last
+        out["jiT_end_s%d" % strat] = jit_rec[-1].astype(np.int32)
+        out["alive_end_s%d" % strat] = alive_rec[-1]
+        out["codes_s%d" % strat] = codes
+    save("g6b_traj_fast.npz", mesh=np.array([Nj, Ni, dkm, warp]), fields=np.array([K, 777, 2.2, 0.6, 0.2]),
+         tmask_boxes=np.array([[40, 46, 60, 70], [80, 83, 20, 50]]), u_sum=np.float64(u.astype(np.float64).sum()),
+         sic_sum=np.float64(sic.astype(np.float64).sum()), yx0=yx0, jiT0=jiT0.astype(np.int32),
+         kstrt=np.int64(kstrt), Nt=np.int64(Nt), rdt=np.float64(rdt), **out)
+
+
 # --------------------------------------------------------------------------- G7
 def h5_values(path, name, fmt):
     txt = subprocess.run(["/opt/conda/bin/h5dump", "-m", fmt, "-d", name, path], check=True,
@@ -539,7 +604,7 @@ def g10_nemoseed():
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, fn in (("g1", g1_inside), ("g2", g2_intersect), ("g3", g3_crossing), ("g4", g4_survive),
-                     ("g5", g5_seedinit), ("g5b", g5b_seedinit_on_points), ("g5c", g5c_seedinit_larger_mesh), ("g6", g6_trajectories), ("g7", g7_projection), ("g8", g8_timespan),
+                     ("g5", g5_seedinit), ("g5b", g5b_seedinit_on_points), ("g5c", g5c_seedinit_larger_mesh), ("g6", g6_trajectories), ("g6b", g6b_fast_flow_trajectories), ("g7", g7_projection), ("g8", g8_timespan),
                      ("g9", g9_haversine), ("g10", g10_nemoseed)):
         if not only or name in only:
             fn()

@@ -134,6 +134,40 @@ def test_survive_bytes_of_resident_records_both_kernels(fdt):
         assert np.array_equal(st["yx"], ref.pos) and np.array_equal(st["vJIt"], ref.jiT) and np.array_equal(st["iAlive"], ref.alive), key
 
 
+@pytest.mark.parametrize("strat", [1, 0])
+@pytest.mark.parametrize("mode", ["step", "run", "run_unsorted"])
+def test_g6b_fast_flow_golden_trajectories(golden, strat, mode):
+    """G6b on the device: the reference's fast-flow trajectories (up to two cells per record; tens of thousands of fall-through
+    crossings) record by record with per-record digests, and through fused launches (sorted with periodic re-sorts: buoys leave
+    the LDS patch all the time; unsorted: no patch) by the final state."""
+    from conftest import g6b_case, traj_digest_row
+    g = golden("g6b_traj_fast.npz")
+    grid, u, v, sic = g6b_case(g)
+    K, kstrt, Nt = u.shape[0], int(g["kstrt"]), int(g["Nt"])
+    trk = make_tracker(grid, grid["tmask"], K, rdt=float(g["rdt"]), iUVstrategy=strat)
+    try:
+        trk.set_buoys(g["yx0"], g["jiT0"], sort=(mode != "run_unsorted"))
+        trk.ctx.set_resort(0 if mode == "run_unsorted" else 7)
+        for k in range(K):
+            trk.load_record(k, u[k], v[k], sic[k])
+        if mode == "step":
+            dg = g["digest_s%d" % strat]
+            for jt in range(Nt):
+                jrec = jt + kstrt
+                trk.step(jrec, jrec % K)
+                pn, mn = trk.record(jrec)
+                st = trk.state()
+                assert np.array_equal(traj_digest_row(pn, mn, st["vJIt"], st["iAlive"]), dg[jt + 1]), jt
+        else:
+            trk.ctx.run(kstrt % K, kstrt, Nt)
+        st = trk.state()
+        alive = st["iAlive"] == 1
+        assert np.array_equal(st["vJIt"], g["jiT_end_s%d" % strat]) and np.array_equal(st["iAlive"], g["alive_end_s%d" % strat])
+        assert np.array_equal(st["yx"], g["last_pos_s%d" % strat]) and 0.3 < alive.mean() < 0.8
+    finally:
+        trk.close()
+
+
 @pytest.mark.parametrize("tag", ["curvi", "regular"])
 @pytest.mark.parametrize("strat", [1, 0])
 @pytest.mark.parametrize("sort", [True, False])

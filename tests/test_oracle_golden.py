@@ -177,6 +177,27 @@ def test_g6_trajectories_bit_exact(golden, tag, strat):
     assert tr.ncross == int(g["codes_s%d" % strat].sum())
 
 
+@pytest.mark.parametrize("strat", [1, 0])
+def test_g6b_fast_flow_trajectories_bit_exact(golden, strat):
+    """G6b: 1 500 buoys x 90 records of a flow of up to two cells per record through the restated reference loop -- 36 000 of the
+    77 000 crossings return code 4, most of them `CrossedEdge`'s fall-through, after which the reference keeps a buoy in a cell
+    that does not contain it.  The oracle must walk the same path: per-record digests (positions bit for bit, masks, cells, alive)."""
+    from conftest import g6b_case, traj_digest_row
+    g = golden("g6b_traj_fast.npz")
+    grid, u, v, sic = g6b_case(g)
+    K, kstrt, Nt = u.shape[0], int(g["kstrt"]), int(g["Nt"])
+    tr = orc.Tracker(grid, g["yx0"], g["jiT0"].astype(np.int64), rdt=float(g["rdt"]), uv_strategy=strat, nthreads=4)
+    dg = g["digest_s%d" % strat]
+    last = g["yx0"].copy()
+    for jt in range(Nt):
+        jrec = jt + kstrt
+        pn, mn = tr.step(jrec, u[jrec % K].astype(np.float64), v[jrec % K].astype(np.float64), sic[jrec % K].astype(np.float64))
+        assert np.array_equal(traj_digest_row(pn, mn, tr.jiT, tr.alive), dg[jt + 1]), jt
+        last[mn == 1] = pn[mn == 1]
+    assert np.array_equal(last, g["last_pos_s%d" % strat]) and np.array_equal(tr.jiT, g["jiT_end_s%d" % strat])
+    assert np.array_equal(tr.alive, g["alive_end_s%d" % strat]) and tr.ncross == int(g["codes_s%d" % strat].sum())
+
+
 def test_g7_forward_projection_matches_reference_fixture(golden):
     # tools/nc/sitrack_seeding_sidfex_19961215_00_HSS5.nc__KEEP: (lat,lon) f4 -> (y_pos,x_pos) f4 made by the
     # reference's cartopy forward projection from tools/sidfexloc.dat
