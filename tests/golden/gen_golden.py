@@ -163,6 +163,26 @@ def g4_survive():
     save("g4_survive.npz", tmask=tmask, sic=sic, sic32=sic32, jiT=jiT, kill_a=k1, kill_b=k2, kill_c=k3)
 
 
+def g4b_survive_wide():
+    """`Survive` for every cell of a mesh whose rows are 16-byte aligned and wider than one strip of the device's register-rolling
+    kernel (44 x 252: strip boundary at column 248), and of a 40 x 48 one: mask values other than 0/1 (a 5-point sum can reach 5
+    with a land point in it), ice exactly at / around the threshold, the asymmetric [j-1,i-1] stencil point."""
+    rng = np.random.default_rng(1243)
+    out = {}
+    for tag, (Nj, Ni) in (("a", (44, 252)), ("b", (40, 48))):
+        tmask = (rng.random((Nj, Ni)) > 0.08).astype(np.int8)
+        tmask[rng.integers(2, Nj - 2, 8), rng.integers(2, Ni - 2, 8)] = 2
+        tmask[rng.integers(2, Nj - 2, 8), rng.integers(2, Ni - 2, 8)] = -1
+        sic = rng.choice([0.0, 0.05, 0.0999, 0.1, 0.1001, 0.12, 0.5, 1.0], size=(Nj, Ni)).astype(np.float64)
+        sic32 = rng.uniform(0.05, 0.16, (Nj, Ni)).astype(np.float32)
+        with quiet():
+            k1 = np.array([[tracking.Survive(0, [j, i], tmask, pIceC=sic) for i in range(Ni)] for j in range(Nj)], dtype=np.int8)
+            k2 = np.array([[tracking.Survive(0, [j, i], tmask, pIceC=sic32.astype(np.float64)) for i in range(Ni)] for j in range(Nj)], dtype=np.int8)
+        print("   G4b %s: killed %.2f / %.2f of the interior" % (tag, k1[2:-2, 2:-2].mean(), k2[2:-2, 2:-2].mean()))
+        out.update({tag + "_tmask": tmask, tag + "_sic": sic, tag + "_sic32": sic32, tag + "_kill": k1, tag + "_kill32": k2})
+    save("g4b_survive_wide.npz", **out)
+
+
 # --------------------------------------------------------------------------- G5
 def polar_grid(Nj, Ni, dkm, warp, yc=-300., xc=200.):
     """Synthetic grid placed near the pole; lat/lon of T-points from the build's own
@@ -603,7 +623,7 @@ def g10_nemoseed():
 
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for name, fn in (("g1", g1_inside), ("g2", g2_intersect), ("g3", g3_crossing), ("g4", g4_survive),
+    for name, fn in (("g1", g1_inside), ("g2", g2_intersect), ("g3", g3_crossing), ("g4", g4_survive), ("g4b", g4b_survive_wide),
                      ("g5", g5_seedinit), ("g5b", g5b_seedinit_on_points), ("g5c", g5c_seedinit_larger_mesh), ("g6", g6_trajectories), ("g6b", g6b_fast_flow_trajectories), ("g7", g7_projection), ("g8", g8_timespan),
                      ("g9", g9_haversine), ("g10", g10_nemoseed)):
         if not only or name in only:

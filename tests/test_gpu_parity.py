@@ -62,6 +62,25 @@ def test_g4_survive_on_device(golden, ctx):
         assert np.array_equal(mask.ravel(), g[key].astype(np.int8)), key     # jiT in G4 enumerates the grid in C order
 
 
+@pytest.mark.parametrize("tile", [0, 1])
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g4b_survive_reference_golden_both_kernels(golden, ctx, tag, tile):
+    """G4b: the REFERENCE's `Survive` for every cell of a 44 x 252 and a 40 x 48 mesh (rows 16-byte aligned: the register-rolling
+    kernel, with a strip boundary inside the wide one) through `sitrk_survive_mask`, i.e. the very kernel that derives a resident
+    record's bytes -- and through the LDS-tile kernel (knob)."""
+    g = golden("g4b_survive_wide.npz")
+    tm = g[tag + "_tmask"]
+    z = np.zeros(tm.shape)
+    ctx.set_grid(z, z, z, z, z, z, tm)
+    ctx.set_params(3600., 1, 0.1)
+    ctx.set_tuning(survive_tile=tile)
+    try:
+        for sic, key in ((g[tag + "_sic"], "_kill"), (g[tag + "_sic32"].astype(np.float64), "_kill32")):
+            assert np.array_equal(ctx.survive_mask(sic), g[tag + key]), key
+    finally:
+        ctx.set_tuning(survive_tile=0)
+
+
 @pytest.mark.parametrize("shape", [(37, 44), (70, 252), (66, 500), (40, 46)])
 def test_survive_kernels_agree_with_the_oracle_on_every_cell(ctx, shape):
     """`Survive` for every cell through both device forms -- the register-rolling kernel (meshes with Ni % 4 == 0: a wave walks

@@ -75,6 +75,16 @@ def test_g9_haversine(golden):
     assert np.all(d[:50] == 0.0)
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g4b_survive_every_cell_of_wide_meshes(golden, tag):
+    g = golden("g4b_survive_wide.npz")
+    tm = g[tag + "_tmask"]
+    Nj, Ni = tm.shape
+    for sic, key in ((g[tag + "_sic"], "_kill"), (g[tag + "_sic32"].astype(np.float64), "_kill32")):
+        got = np.array([[orc.Survive((j, i), tm, sic) for i in range(Ni)] for j in range(Nj)], dtype=np.int8)
+        assert np.array_equal(got, g[tag + key])
+
+
 def test_g5_nearest_point_and_cells(golden):
     g = golden("g5_seedinit.npz")
     nP = len(g["ids"])
