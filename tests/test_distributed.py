@@ -142,6 +142,87 @@ def _a2a_worker(rank, world, port, q):
         comm.close()
 
 
+def _world8_worker(rank, world, port, q):
+    """everything the 8-GPU run of BASELINE config 4 exchanges, with 8 gloo ranks on the CPU: identity gather, slab broadcast and
+    scatter + all-gather of a slab whose length is not a multiple of 8, buoy ranges incl. fewer buoys than ranks, the
+    all-to-all migration, reductions -- and the oracle stepping every rank's range"""
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle as orc
+    from sitrack_amd.distributed import Comm
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), SITRK_DIST_BACKEND="gloo")
+    comm = Comm()
+    try:
+        ok = comm.world == 8 and comm.multi
+        ids = comm.allgather_obj((rank, os.getpid()))
+        ok = ok and [r for r, _ in ids] == list(range(8)) and len({p for _, p in ids}) == 8
+        # slab exchange both ways
+        for n in (3 * 37 * 41, 1000):
+            want = torch.arange(n, dtype=torch.float32) * 0.25 - 3.0
+            t = want.clone() if rank == 0 else torch.zeros(n)
+            sd.scatter_allgather(t, src=0)
+            t2 = want.clone() if rank == 0 else torch.zeros(n)
+            dist.broadcast(t2, src=0)
+            ok = ok and bool(torch.equal(t, want)) and bool(torch.equal(t2, want))
+        # ranges, gathers
+        for nP in (0, 5, 8, 1003):
+            lo, hi = sd.buoy_range(nP, rank, world)
+            arr = np.arange(2 * nP, dtype=np.float64).reshape(nP, 2) * 0.5
+            got = sd.gather_ranges(arr[lo:hi], nP)
+            ok = ok and ((got is None) if rank else np.array_equal(got, arr))
+        assert sd.all_ranges(1003, 8)[-1][1] == 1003 and sum(h - l for l, h in sd.all_ranges(1003, 8)) == 1003
+        # migration
+        rng = np.random.default_rng(200 + rank)
+        n = [0, 7, 1000, 3, 250, 1, 64, 500][rank]
+        f8 = rng.random((n, 3)); dest = rng.integers(0, world, n)
+        (got_f8,) = comm.alltoall_rows([(f8[dest == d],) for d in range(world)])
+        everything = comm.allgather_obj((f8, dest))
+        ok = ok and np.array_equal(got_f8, np.concatenate([e[0][e[1] == rank] for e in everything]))
+        ok = ok and list(comm.allreduce_sum(np.array([rank + 1], dtype=np.int64))) == [36]
+        # partition + per-record slab broadcast + gather, the oracle stepping each range
+        Nj, Ni, K, Nt = 40, 48, 3, 8
+        grid = syn.make_grid(Nj, Ni, dkm=4.0, warp=1.0)
+        _, yx = syn.make_buoys(grid, 700, seed=9, frac=0.6)
+        guess = syn.nearest_t_plane(grid, yx)
+        good = np.zeros(len(yx), dtype=bool); ji = np.zeros((len(yx), 2), dtype=np.int64)
+        for b in range(len(yx)):
+            good[b], ji[b], _ = orc.FindContainingCell(yx[b], guess[b], grid["Yf"], grid["Xf"])
+        yx, ji = yx[good], ji[good]
+        lo, hi = sd.buoy_range(len(yx), rank, world)
+        mine = orc.Tracker(grid, yx[lo:hi], ji[lo:hi])
+        fields = syn.make_fields(grid, K=K, seed=4, umax=0.7, drift=0.2, ripple=0.1) if rank == 0 else None
+        for jrec in range(Nt):
+            slab = sd.pack_slab(fields[0][jrec % K], fields[1][jrec % K], fields[2][jrec % K], np.float32) if rank == 0 else None
+            u, v, s_ = sd.split_slab(sd.broadcast_record_host(slab, 3 * Nj * Ni, np.float32, src=0), Nj, Ni)
+            mine.step(jrec, u, v, s_, want_out=False)
+        pos = sd.gather_ranges(mine.pos, len(yx)); cells = sd.gather_ranges(mine.jiT, len(yx))
+        if rank == 0:
+            ref = orc.Tracker(grid, yx, ji)
+            for jrec in range(Nt):
+                ref.step(jrec, fields[0][jrec % K], fields[1][jrec % K], fields[2][jrec % K], want_out=False)
+            ok = ok and np.array_equal(pos, ref.pos) and np.array_equal(cells, ref.jiT) and ref.ncross > 50
+        q.put((rank, bool(ok)))
+    finally:
+        comm.close()
+
+
+def test_world8_gloo_rehearsal_of_the_8_gpu_exchange():
+    """BASELINE config 4 runs on 8 ranks; the driver launches that, not the builder.  Its rank arithmetic and every exchange
+    primitive with EIGHT ranks (gloo, CPU): see _world8_worker."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_world8_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(8)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r for r, _ in res) == list(range(8)) and all(ok for _, ok in res), res
+
+
 def test_alltoall_rows_world3_gloo():
     """the migration primitive of the re-balancing (Comm.alltoall_rows): rows for every destination, received in
     source-rank order; gloo has no all-to-all, so this is the isend / irecv form"""
