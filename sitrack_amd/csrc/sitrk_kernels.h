@@ -789,15 +789,23 @@ __device__ __forceinline__ void resolve_crossing_lds(pt P1, pt P2, pt bl, pt br,
                                                      const int *__restrict__ tab, const int *__restrict__ tabL, int &dcell, int &dk,
                                                      int &dlo, bool &killed)
 {
+#ifdef SITRK_ABL_NOEDGE                 // ablation (timing only, WRONG results): the crossed edge from one comparison instead of CrossedEdge
+    const unsigned ro = (P2.x > ur.x) ? 64u : ((P2.y > ur.y) ? 128u : ((P2.y <= bl.y) ? 0u : 192u));
+#else
     const bool sbl = ccw(P1, P2, bl), sbr = ccw(P1, P2, br), sur = ccw(P1, P2, ur), sul = ccw(P1, P2, ul);
     const bool h1 = (ccw(P1, bl, br) != ccw(P2, bl, br)) && (sbl != sbr);
     const bool h2 = (ccw(P1, br, ur) != ccw(P2, br, ur)) && (sbr != sur);
     const bool h3 = (ccw(P1, ur, ul) != ccw(P2, ur, ul)) && (sur != sul);
     const unsigned ro = h1 ? 0u : (h2 ? 64u : (h3 ? 128u : 192u));            // both tables have 64-byte rows
+#endif
     const int *row = (const int *)((const char *)tab + ro), *rowL = (const int *)((const char *)tabL + ro);
     const int4 r1 = *(const int4 *)(row + 4), r2 = *(const int4 *)(row + 8);
     const int bB = row[12];
     const int4 l0 = *(const int4 *)(rowL), l1 = *(const int4 *)(rowL + 4);
+#ifdef SITRK_ABL_NODIAG                 // ablation (timing only, WRONG results): no NewHostCell tests, no extension points
+    bool hitA = false, hitB = false;
+    (void)l0;
+#else
     const pt va = lds_pt_at(lo + (unsigned)l0.x), vb = lds_pt_at(lo + (unsigned)l0.y);     // (the table's offsets carry the bias)
     const pt eA = lds_pt_at(lo + (unsigned)l0.z), eB = lds_pt_at(lo + (unsigned)l0.w);
     bool hitA = ccw(P1, va, eA) != ccw(P2, va, eA);
@@ -806,6 +814,7 @@ __device__ __forceinline__ void resolve_crossing_lds(pt P1, pt P2, pt bl, pt br,
         hitA = hitA && (ccw(P1, P2, va) != ccw(P1, P2, eA));
         hitB = hitB && (ccw(P1, P2, vb) != ccw(P1, P2, eB));
     }
+#endif
     dcell = hitA ? r1.y : (hitB ? r1.z : r1.x);
     dk = hitA ? r2.x : (hitB ? r2.y : r1.w);
     dlo = hitA ? l1.y : (hitB ? l1.z : l1.x);
@@ -939,10 +948,19 @@ __global__ __launch_bounds__(kRunBlock, WINDOW ? SITRK_RUN_WAVES_WINDOW : SITRK_
             if (jrec > last) break;
         }
         // the four velocity candidates u[jT,iT-1], u[jT,iT], v[jT-1,iT], v[jT,iT]
+#ifdef SITRK_ABL_VEL2                   // ablation (timing only, WRONG results): two velocity loads instead of three
+        FT fu1 = *(const FT *)(ub + x.o1), fu0 = fu1;
+        FT fv1 = *(const FT *)(vb + x.o1), fv0 = fv1;
+#else
         FT fu0 = *(const FT *)(ub + x.o1 - sizeof(FT)), fu1 = *(const FT *)(ub + x.o1);
         FT fv0 = *(const FT *)(vb + (x.o1 - (unsigned)a.Ni * (unsigned)sizeof(FT))), fv1 = *(const FT *)(vb + x.o1);
+#endif
         // ... and the Survive byte of the cell's 8 neighbours for this record (used only if the buoy leaves the cell)
+#ifdef SITRK_ABL_NOK9                   // ablation (timing only, WRONG results): no Survive byte
+        unsigned k9 = 0; (void)kb;
+#else
         unsigned k9 = *(const uint8_t *)(kb + (x.o1 >> (sizeof(FT) == 4 ? 2 : 3)));
+#endif
         double zU, zV;
         FT su = 0, sv = 0;                               // UVS == 1: the selected candidates as loaded
         if (UVS == 0) {                                  // :423-425
