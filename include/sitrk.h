@@ -143,6 +143,30 @@ int sitrk_push_record_rows(sitrk_t *h, int slot, int j0, int j1, const void *u_r
 /* same derivation for rows [j0,j1) that the caller wrote in place through sitrk_record_ptr (device-side copies) */
 int sitrk_commit_record_rows(sitrk_t *h, int slot, int j0, int j1);
 
+/* Box ingest (rows AND columns).  The same argument in both directions: a step of a buoy hosted by (jT,iT) reads u,v in
+ * rows jT-1..jT / columns iT-1..iT and Survive bytes of the cells (jT-1..jT+1, iT-1..iT+1), which derive from siconc in
+ * (jT-2..jT+2, iT-2..iT+2); UpdtInd4NewCell moves a host cell by at most one row and one column per record.  With
+ * (jmin,jmax,imin,imax) = sitrk_buoy_box() the next step can only touch the box rows [jmin-2, jmax+3) x columns
+ * [imin-2, imax+3) of a record (36 % of the cells of BASELINE config 3, whose buoys fill the central 60 % x 60 %):
+ *   sitrk_push_record_box     host arrays holding exactly the box, densely packed (j1-j0) x (i1-i0) -> slot (three strided
+ *                             DMAs out of the library's pinned staging), + the Survive bytes the box determines
+ *   sitrk_stage_acquire_box / sitrk_stage_submit_box   the same for a reader that fills the pinned staging itself
+ *                             (a NetCDF hyperslab read of si3_part_tracker.py:372-374 restricted to the box)
+ *   sitrk_commit_record_box   the slab already sits in device memory (written through sitrk_record_ptr: an RCCL broadcast, a
+ *                             device-side producer): derive the Survive bytes of the box only, and treat the slot as holding
+ *                             that box from now on
+ * The library remembers the box a slot holds and checks every step against it exactly like the row bands: age records after
+ * sitrk_buoy_box() the slot must hold rows [jmin-2-age, jmax+3+age) and columns [imin-2-age, imax+3+age), else SITRK_EINVAL.
+ * sitrk_buoy_rows() evaluates the columns too (a row band is a box of full width). */
+int sitrk_buoy_box(sitrk_t *h, int32_t *jmin, int32_t *jmax, int32_t *imin, int32_t *imax);
+int sitrk_push_record_box(sitrk_t *h, int slot, int j0, int j1, int i0, int i1, const void *u_box, const void *v_box, const void *sic_box);
+int sitrk_stage_acquire_box(sitrk_t *h, int nrows, int ncols, void **u, void **v, void **sic);
+int sitrk_stage_submit_box(sitrk_t *h, int slot, int j0, int j1, int i0, int i1);
+int sitrk_commit_record_box(sitrk_t *h, int slot, int j0, int j1, int i0, int i1);
+/* the same box of the nrec records in slots (slot0 + k) % nslots, k < nrec (the slots a sitrk_run of nrec records from slot0
+ * steps with), derived by ONE launch: a box of a record is ~10 us of memory traffic, of the order of a dependent dispatch */
+int sitrk_commit_records_box(sitrk_t *h, int slot0, int nrec, int j0, int j1, int i0, int i1);
+
 /* ---- buoys ---------------------------------------------------------------
  * State of si3_part_tracker.py:324-330 reduced to what the loop reads:
  * yx = xPosC[jt] (nP,2) km; jiT = vJIt (nP,2); rec_first/rec_last =
@@ -154,8 +178,9 @@ int sitrk_set_buoys(sitrk_t *h, int64_t nP, const double *yx, const int32_t *jiT
                     const int32_t *rec_first, const int32_t *rec_last);
 
 /* Buoys that arrive with a history (handed over by another rank when the ranks' latitude bands are re-balanced): right after
- * sitrk_set_buoys, mark the buoys with alive[k] == 0 as dead and give every buoy its kill record back (kill_rec[k], -1 =
- * alive), so that sitrk_fetch / sitrk_fetch_record answer as they did on the rank that stepped them before. */
+ * sitrk_set_buoys, mark the buoys with alive[k] == 0 as dead and give every DEAD buoy its kill record back (kill_rec[k]), so
+ * that sitrk_fetch / sitrk_fetch_record answer as they did on the rank that stepped them before.  Invariant of the library:
+ * a buoy is alive exactly when its kill record is -1 -- kill_rec[k] of a buoy with alive[k] != 0 is ignored (stored as -1). */
 int sitrk_restore_state(sitrk_t *h, const int8_t *alive, const int32_t *kill_rec);
 
 /* re-order the device-resident buoys by host cell (coalescing); results are

@@ -44,6 +44,12 @@ _SIGNATURES = {
     "sitrk_buoy_rows": (_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sitrk_push_record_rows": (_int, [_vp, _int, _int, _int, _vp, _vp, _vp]),
     "sitrk_commit_record_rows": (_int, [_vp, _int, _int, _int]),
+    "sitrk_buoy_box": (_int, [_vp] + [C.POINTER(C.c_int32)] * 4),
+    "sitrk_push_record_box": (_int, [_vp, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
+    "sitrk_stage_acquire_box": (_int, [_vp, _int, _int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "sitrk_stage_submit_box": (_int, [_vp, _int, _int, _int, _int, _int]),
+    "sitrk_commit_record_box": (_int, [_vp, _int, _int, _int, _int, _int]),
+    "sitrk_commit_records_box": (_int, [_vp, _int, _int, _int, _int, _int, _int]),
     "sitrk_record_ptr": (_vp, [_vp, _int]),
     "sitrk_commit_record": (_int, [_vp, _int]),
     "sitrk_set_buoys": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
@@ -225,19 +231,23 @@ class Context:
         # asynchronous: the library copies the fields into its pinned staging before returning (temporaries are fine)
         self._chk(self._L.sitrk_push_record(self._h, int(slot), _ptr(u), _ptr(v), _ptr(sic)))
 
-    def stage(self, nrows=None):
-        """The library's next pinned staging buffer as three (nrows, Ni) arrays of the records' dtype: read the record
-        straight into them, then submit(slot, j0).  The arrays are VIEWS of pinned host memory the library owns: valid
-        until submit() / stage_release(), and dangling after alloc_records(), set_grid() or close(), which free it.
-        Prefer stage_fill(), which also releases the buffer when the read fails."""
+    def stage(self, nrows=None, ncols=None):
+        """The library's next pinned staging buffer as three (nrows, ncols) arrays of the records' dtype (ncols = Ni unless
+        a box is staged): read the record straight into them, then submit(slot, j0[, i0]).  The arrays are VIEWS of pinned
+        host memory the library owns: valid until submit() / stage_release(), and dangling after alloc_records(),
+        set_grid() or close(), which free it.  Prefer stage_fill(), which also releases the buffer when the read fails."""
         nrows = self.Nj if nrows is None else int(nrows)
+        ncols = self.Ni if ncols is None else int(ncols)
         pu, pv, ps = _vp(), _vp(), _vp()
-        self._chk(self._L.sitrk_stage_acquire(self._h, nrows, C.byref(pu), C.byref(pv), C.byref(ps)))
-        nb = nrows * self.Ni * self.field_dtype.itemsize
+        if ncols == self.Ni:
+            self._chk(self._L.sitrk_stage_acquire(self._h, nrows, C.byref(pu), C.byref(pv), C.byref(ps)))
+        else:
+            self._chk(self._L.sitrk_stage_acquire_box(self._h, nrows, ncols, C.byref(pu), C.byref(pv), C.byref(ps)))
+        nb = nrows * ncols * self.field_dtype.itemsize
 
         def view(p):
-            return np.frombuffer((C.c_char * nb).from_address(p.value), dtype=self.field_dtype).reshape(nrows, self.Ni)
-        self._staged_rows = nrows
+            return np.frombuffer((C.c_char * nb).from_address(p.value), dtype=self.field_dtype).reshape(nrows, ncols)
+        self._staged_rows, self._staged_cols = nrows, ncols
         return view(pu), view(pv), view(ps)
 
     def stage_release(self):
@@ -245,10 +255,10 @@ class Context:
         be used any more, the next stage() hands out the same buffer."""
         self._chk(self._L.sitrk_stage_release(self._h))
 
-    def stage_fill(self, slot, j0, nrows, fill):
-        """stage() + fill(u, v, sic) + submit(slot, j0), exception safe: if `fill` raises, the buffer is released, so the
+    def stage_fill(self, slot, j0, nrows, fill, i0=0, ncols=None):
+        """stage() + fill(u, v, sic) + submit(slot, j0, i0), exception safe: if `fill` raises, the buffer is released, so the
         context stays usable (a later stage()/push_record is not refused with 'not submitted')."""
-        bufs = self.stage(nrows)
+        bufs = self.stage(nrows, ncols)
         try:
             fill(*bufs)
         except BaseException:
@@ -256,11 +266,16 @@ class Context:
             raise
         finally:
             del bufs                                     # the views die with the hand-out
-        self.submit(slot, j0)
+        self.submit(slot, j0, i0)
 
-    def submit(self, slot, j0=0):
-        """Queue the staged rows as rows [j0, j0+nrows) of `slot` (asynchronous, see sitrk_stage_submit)."""
-        self._chk(self._L.sitrk_stage_submit(self._h, int(slot), int(j0), int(j0) + int(self._staged_rows)))
+    def submit(self, slot, j0=0, i0=0):
+        """Queue the staged box as rows [j0, j0+nrows) x columns [i0, i0+ncols) of `slot` (asynchronous, see
+        sitrk_stage_submit / sitrk_stage_submit_box)."""
+        j1, i1 = int(j0) + int(self._staged_rows), int(i0) + int(self._staged_cols)
+        if int(i0) == 0 and i1 == self.Ni:
+            self._chk(self._L.sitrk_stage_submit(self._h, int(slot), int(j0), j1))
+        else:
+            self._chk(self._L.sitrk_stage_submit_box(self._h, int(slot), int(j0), j1, int(i0), i1))
 
     def launch_stats(self, reset=False):
         a, b, c = _i64(0), _i64(0), _i64(0)
@@ -280,6 +295,41 @@ class Context:
         if jmin > jmax:
             return 0, 0
         return max(0, jmin - 2 - age), min(self.Nj, jmax + 3 + age)
+
+    def buoy_box(self):
+        """(jmin, jmax, imin, imax) of the host cells of the buoys still alive; jmin > jmax when there is none."""
+        v = [C.c_int32(0) for _ in range(4)]
+        self._chk(self._L.sitrk_buoy_box(self._h, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
+
+    def box(self, age=0, align=4):
+        """The box (j0, j1, i0, i1) of a record the next step(s) can touch: rows [jmin-2-age, jmax+3+age) x columns
+        [imin-2-age, imax+3+age) clipped to the grid, the columns widened to multiples of `align` (16-byte lines of an fp32
+        row).  `age` = records stepped since (a host cell moves at most one row and one column per record)."""
+        jmin, jmax, imin, imax = self.buoy_box()
+        return self.box_of(jmin, jmax, imin, imax, age, align)
+
+    def box_of(self, jmin, jmax, imin, imax, age=0, align=4):
+        if jmin > jmax:
+            return 0, 0, 0, 0
+        i0, i1 = max(0, imin - 2 - age), min(self.Ni, imax + 3 + age)
+        i0 -= i0 % align
+        i1 = min(self.Ni, -(-i1 // align) * align)
+        return max(0, jmin - 2 - age), min(self.Nj, jmax + 3 + age), i0, i1
+
+    def push_record_box(self, slot, j0, j1, i0, i1, u_box, v_box, sic_box):
+        shp = (j1 - j0, i1 - i0)
+        u = as_c(u_box, self.field_dtype, shp, "u box")
+        v = as_c(v_box, self.field_dtype, shp, "v box")
+        s = as_c(sic_box, self.field_dtype, shp, "sic box")
+        self._chk(self._L.sitrk_push_record_box(self._h, int(slot), int(j0), int(j1), int(i0), int(i1), _ptr(u), _ptr(v), _ptr(s)))
+
+    def commit_record_box(self, slot, j0, j1, i0, i1):
+        self._chk(self._L.sitrk_commit_record_box(self._h, int(slot), int(j0), int(j1), int(i0), int(i1)))
+
+    def commit_records_box(self, slot0, nrec, j0, j1, i0, i1):
+        """commit_record_box for the nrec slots (slot0 + k) % nslots in one launch"""
+        self._chk(self._L.sitrk_commit_records_box(self._h, int(slot0), int(nrec), int(j0), int(j1), int(i0), int(i1)))
 
     def push_record_rows(self, slot, j0, j1, u_rows, v_rows, sic_rows):
         shp = (j1 - j0, self.Ni)

@@ -113,7 +113,7 @@ SITRK_API int sitrk_create(sitrk_t **out, int device)
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     for (int b = 0; b < sitrk_ctx::kStage && e == hipSuccess; b++) e = hipEventCreateWithFlags(&c->stage_done[b], hipEventDisableTiming);
     for (int k = 0; k < sitrk_ctx::kLaunchRing && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->launch_ev[k], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMalloc((void **)&c->counter, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->counter, 4 * sizeof(unsigned long long));     // reductions: up to 4 ints / one 64-bit count
     if (e != hipSuccess) {
         int rc = fail(h, SITRK_EHIP, "sitrk_create: %s", hipGetErrorString(e));
         (void)sitrk_destroy(c);                 // releases whatever was created before the failure
@@ -281,10 +281,14 @@ static void free_records(sitrk_ctx *h)
         if (h->stage[b]) (void)hipHostFree(h->stage[b]);
         h->stage[b] = nullptr;
     }
-    h->stage_bytes = 0; h->stage_rows = -1; h->stage_next = 0;
+    h->stage_bytes = 0; h->stage_rows = -1; h->stage_cols = 0; h->stage_next = 0;
     memset(h->slot_pending, 0, sizeof(h->slot_pending));
     memset(h->slot_dirty, 1, sizeof(h->slot_dirty));
-    for (int k = 0; k < 4096; k++) { h->slot_used_seq[k] = -1; h->slot_row_lo[k] = h->slot_row_hi[k] = 0; }
+    for (int k = 0; k < 4096; k++) {
+        h->slot_used_seq[k] = -1;
+        h->slot_row_lo[k] = h->slot_row_hi[k] = 0;
+        h->slot_col_lo[k] = h->slot_col_hi[k] = 0;
+    }
 }
 
 SITRK_API int sitrk_alloc_records(sitrk_t *h, int nslots, int dtype)
@@ -319,6 +323,7 @@ SITRK_API void *sitrk_record_ptr(sitrk_t *h, int slot)
     if (!h || !h->slabs || slot < 0 || slot >= h->nslots) return nullptr;
     h->slot_dirty[slot] = 1;            // the caller is about to write the slab
     h->slot_row_lo[slot] = 0; h->slot_row_hi[slot] = h->Nj;     // until a commit says otherwise
+    h->slot_col_lo[slot] = 0; h->slot_col_hi[slot] = h->Ni;
     return slab_of(h, slot);
 }
 
@@ -342,45 +347,79 @@ static int launch_mark(sitrk_ctx *h, const int *slots, int nslots_used)
     return SITRK_OK;
 }
 
-// Survive bytes + packed neighbourhoods of rows [j0,j1) from the siconc rows [v0,v1) of `sic` (device pointer, f64 or f32), one pass
-static int launch_survive(sitrk_ctx *h, bool f64, const void *sic, int8_t *kill, uint8_t *kill9, int j0, int j1, int v0, int v1)
+// Survive bytes + packed neighbourhoods of the box rows [j0,j1) x columns [i0,i1) of `nb` records whose siconc is valid in
+// exactly that box, one pass, ONE launch: record k's siconc field is sic + slots[k] * sic_stride elements, its Survive arrays
+// kill / kill9 + slots[k] * kill_stride bytes (f64 or f32; a probe passes one record with strides 0)
+static int launch_survive(sitrk_ctx *h, bool f64, const void *sic, int8_t *kill, uint8_t *kill9, int j0, int j1, int i0, int i1,
+                          const int *slots = nullptr, int nb = 1, long long sic_stride = 0, long long kill_stride = 0)
 {
+    SvBox bx;
+    bx.j_lo = j0; bx.j_hi = j1; bx.v_lo = j0; bx.v_hi = j1;
+    bx.cv_lo = i0; bx.cv_hi = i1;
+    bx.c_lo = i0 & ~3;                                   // 4-byte aligned output strips (both kernels store 32-bit words when Ni % 4 == 0)
+    SvBatch sb;
+    sb.sic_stride = sic_stride; sb.kill_stride = kill_stride;
+    for (int k = 0; k < kSvMaxBatch; k++) sb.slot[k] = (slots && k < nb) ? slots[k] : 0;
     if ((h->Ni & 3) == 0 && !(h->tune & TUNE_SURVIVE_TILE)) {
         // 16-byte aligned rows: the register-rolling form (no LDS, no barriers; sitrk_kernels.h)
-        const dim3 g((unsigned)((h->Ni + kSvRowsCols - 1) / kSvRowsCols), (unsigned)((j1 - j0 + 4 * kSvRowsR - 1) / (4 * kSvRowsR)));
+        bx.c_hi = (i1 + 3) & ~3;
+        const unsigned gx = (unsigned)((bx.c_hi - bx.c_lo + kSvRowsCols - 1) / kSvRowsCols);
+        // (8 rows per wave instead of 16 for small boxes was measured: no gain alone, 15 % slower in a batch -- profiles/r04b_sv_box.jsonl)
+        const dim3 g(gx, (unsigned)((j1 - j0 + 4 * kSvRowsR - 1) / (4 * kSvRowsR)), (unsigned)nb);
         if (f64)
-            hipLaunchKernelGGL((survive_kill9_rows_kernel<double>), g, dim3(256), 0, h->stream, h->Nj, h->Ni, j0, j1, v0, v1, h->tmask,
+            hipLaunchKernelGGL((survive_kill9_rows_kernel<double>), g, dim3(256), 0, h->stream, h->Nj, h->Ni, bx, sb, h->tmask,
                                (const double *)sic, h->rmin_conc, kill, kill9);
         else
-            hipLaunchKernelGGL((survive_kill9_rows_kernel<float>), g, dim3(256), 0, h->stream, h->Nj, h->Ni, j0, j1, v0, v1, h->tmask,
+            hipLaunchKernelGGL((survive_kill9_rows_kernel<float>), g, dim3(256), 0, h->stream, h->Nj, h->Ni, bx, sb, h->tmask,
                                (const float *)sic, h->rmin_conc, kill, kill9);
     } else {
-        const dim3 grid((unsigned)((h->Ni + kSvTC - 1) / kSvTC), (unsigned)((j1 - j0 + kSvTR - 1) / kSvTR));
+        bx.c_hi = i1;
+        const dim3 grid((unsigned)((bx.c_hi - bx.c_lo + kSvTC - 1) / kSvTC), (unsigned)((j1 - j0 + kSvTR - 1) / kSvTR), (unsigned)nb);
         if (f64)
-            hipLaunchKernelGGL((survive_kill9_kernel<double>), grid, dim3(kSvBlock), 0, h->stream, h->Nj, h->Ni, j0, j1, v0, v1, h->tmask,
+            hipLaunchKernelGGL((survive_kill9_kernel<double>), grid, dim3(kSvBlock), 0, h->stream, h->Nj, h->Ni, bx, sb, h->tmask,
                                (const double *)sic, h->rmin_conc, kill, kill9);
         else
-            hipLaunchKernelGGL((survive_kill9_kernel<float>), grid, dim3(kSvBlock), 0, h->stream, h->Nj, h->Ni, j0, j1, v0, v1, h->tmask,
+            hipLaunchKernelGGL((survive_kill9_kernel<float>), grid, dim3(kSvBlock), 0, h->stream, h->Nj, h->Ni, bx, sb, h->tmask,
                                (const float *)sic, h->rmin_conc, kill, kill9);
     }
     HIPCHK(hipGetLastError());
     return SITRK_OK;
 }
 
-// derive the Survive bytes of rows [j0,j1) of a slot from its siconc rows [v0,v1) (queued on the compute stream)
-static int derive_mask_rows(sitrk_ctx *h, int slot, int j0, int j1, int v0, int v1)
+// derive the Survive bytes of the box rows [j0,j1) x columns [i0,i1) of `nb` slots from their siconc there, in one launch
+// (queued on the compute stream behind the slots' uploads)
+static int derive_mask_box_batch(sitrk_ctx *h, const int *slots, int nb, int j0, int j1, int i0, int i1)
 {
     const size_t n = (size_t)h->Nj * h->Ni, es = elem_size(h->dtype);
-    const char *sic = slab_of(h, slot) + 2 * n * es;
-    int rc = slot_wait_upload(h, slot);
-    if (rc) return rc;
-    rc = launch_survive(h, h->dtype == SITRK_F64, sic, h->kill + (size_t)slot * n, h->kill9 + (size_t)slot * n, j0, j1, v0, v1);
-    if (rc) return rc;
-    h->slot_dirty[slot] = 0;
+    for (int k = 0; k < nb; k++) {
+        int rc = slot_wait_upload(h, slots[k]);
+        if (rc) return rc;
+    }
+    if (!(j0 >= j1 || i0 >= i1)) {                      // (a slot that holds nothing: check_band refuses to step with it)
+        int rc = launch_survive(h, h->dtype == SITRK_F64, (const char *)h->slabs + 2 * n * es, h->kill, h->kill9, j0, j1, i0, i1,
+                                slots, nb, (long long)(h->slab_bytes / es), (long long)n);
+        if (rc) return rc;
+    }
+    for (int k = 0; k < nb; k++) h->slot_dirty[slots[k]] = 0;
     return SITRK_OK;
 }
 
-static int derive_mask(sitrk_ctx *h, int slot) { return derive_mask_rows(h, slot, 0, h->Nj, 0, h->Nj); }
+static int derive_mask_box(sitrk_ctx *h, int slot, int j0, int j1, int i0, int i1)
+{
+    return derive_mask_box_batch(h, &slot, 1, j0, j1, i0, i1);
+}
+
+// a slot that was marked as rewritten in place is re-derived over the box it holds
+static int derive_mask(sitrk_ctx *h, int slot)
+{
+    return derive_mask_box(h, slot, h->slot_row_lo[slot], h->slot_row_hi[slot], h->slot_col_lo[slot], h->slot_col_hi[slot]);
+}
+
+static inline void slot_holds(sitrk_ctx *h, int slot, int j0, int j1, int i0, int i1)
+{
+    h->slot_row_lo[slot] = j0; h->slot_row_hi[slot] = j1;
+    h->slot_col_lo[slot] = i0; h->slot_col_hi[slot] = i1;
+}
 
 SITRK_API int sitrk_commit_record(sitrk_t *h, int slot)
 {
@@ -388,17 +427,13 @@ SITRK_API int sitrk_commit_record(sitrk_t *h, int slot)
     NEED(h->slabs, "sitrk_commit_record: call sitrk_alloc_records first");
     NEED(slot >= 0 && slot < h->nslots, "sitrk_commit_record: slot out of range");
     HIPCHK(hipSetDevice(h->device));
-    h->slot_row_lo[slot] = 0; h->slot_row_hi[slot] = h->Nj;
+    slot_holds(h, slot, 0, h->Nj, 0, h->Ni);
     return derive_mask(h, slot);
 }
 
 // ---- pinned staging + copy stream -------------------------------------------------------------------------
-SITRK_API int sitrk_stage_acquire(sitrk_t *h, int nrows, void **u, void **v, void **sic)
+static int stage_acquire_box(sitrk_ctx *h, int nrows, int ncols, void **u, void **v, void **sic)
 {
-    NEED(h, "null handle");
-    NEED(h->slabs, "sitrk_stage_acquire: call sitrk_alloc_records first");
-    NEED(nrows >= 1 && nrows <= h->Nj, "sitrk_stage_acquire: nrows out of range");
-    NEED(u && v && sic, "sitrk_stage_acquire: null output");
     NEED(h->stage_rows < 0, "sitrk_stage_acquire: the buffer handed out before was not submitted");
     HIPCHK(hipSetDevice(h->device));
     const int b = h->stage_next;
@@ -407,12 +442,62 @@ SITRK_API int sitrk_stage_acquire(sitrk_t *h, int nrows, void **u, void **v, voi
         h->stage_bytes = h->slab_bytes;
     }
     HIPCHK(hipEventSynchronize(h->stage_done[b]));      // the DMA that last read this buffer has finished
-    const size_t nb = (size_t)nrows * h->Ni * elem_size(h->dtype);
+    const size_t nb = (size_t)nrows * ncols * elem_size(h->dtype);
     *u = h->stage[b];
     *v = (char *)h->stage[b] + nb;
     *sic = (char *)h->stage[b] + 2 * nb;
-    h->stage_rows = nrows;
+    h->stage_rows = nrows; h->stage_cols = ncols;
     return SITRK_OK;
+}
+
+SITRK_API int sitrk_stage_acquire(sitrk_t *h, int nrows, void **u, void **v, void **sic)
+{
+    NEED(h, "null handle");
+    NEED(h->slabs, "sitrk_stage_acquire: call sitrk_alloc_records first");
+    NEED(nrows >= 1 && nrows <= h->Nj, "sitrk_stage_acquire: nrows out of range");
+    NEED(u && v && sic, "sitrk_stage_acquire: null output");
+    return stage_acquire_box(h, nrows, h->Ni, u, v, sic);
+}
+
+SITRK_API int sitrk_stage_acquire_box(sitrk_t *h, int nrows, int ncols, void **u, void **v, void **sic)
+{
+    NEED(h, "null handle");
+    NEED(h->slabs, "sitrk_stage_acquire_box: call sitrk_alloc_records first");
+    NEED(nrows >= 1 && nrows <= h->Nj && ncols >= 1 && ncols <= h->Ni, "sitrk_stage_acquire_box: box out of range");
+    NEED(u && v && sic, "sitrk_stage_acquire_box: null output");
+    return stage_acquire_box(h, nrows, ncols, u, v, sic);
+}
+
+// the staged fields travel as the box rows [j0,j1) x columns [i0,i1) of `slot`: full-width boxes as three linear copies,
+// others as three strided (2-D) copies out of the densely packed staging
+static int stage_submit_box(sitrk_ctx *h, int slot, int j0, int j1, int i0, int i1)
+{
+    HIPCHK(hipSetDevice(h->device));
+    const int b = h->stage_next;
+    const size_t n = (size_t)h->Nj * h->Ni, es = elem_size(h->dtype);
+    const int nr = j1 - j0, nc = i1 - i0;
+    const size_t nb = (size_t)nr * nc * es;
+    char *d = slab_of(h, slot);
+    const char *src = (const char *)h->stage[b];
+    // the copy may not overtake kernels that still read the slot; nothing else on the compute stream holds it back
+    if (h->slot_used_seq[slot] >= 0) HIPCHK(hipStreamWaitEvent(h->copy_stream, h->launch_ev[h->slot_used_seq[slot] % sitrk_ctx::kLaunchRing], 0));
+    for (int f = 0; f < 3; f++) {
+        char *df = d + (size_t)f * n * es + ((size_t)j0 * h->Ni + i0) * es;
+        if (nc == h->Ni) HIPCHK(hipMemcpyAsync(df, src + (size_t)f * nb, nb, hipMemcpyHostToDevice, h->copy_stream));
+        else HIPCHK(hipMemcpy2DAsync(df, (size_t)h->Ni * es, src + (size_t)f * nb, (size_t)nc * es, (size_t)nc * es, (size_t)nr,
+                                     hipMemcpyHostToDevice, h->copy_stream));
+    }
+    HIPCHK(hipEventRecord(h->stage_done[b], h->copy_stream));
+    if (!h->slot_ready[slot]) HIPCHK(hipEventCreateWithFlags(&h->slot_ready[slot], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(h->slot_ready[slot], h->copy_stream));
+    h->slot_pending[slot] = 1;
+    h->stage_rows = -1;
+    h->stage_next = (b + 1) % sitrk_ctx::kStage;
+    slot_holds(h, slot, j0, j1, i0, i1);
+    // the Survive bytes this box determines, on the compute stream behind the upload
+    int rc = derive_mask_box(h, slot, j0, j1, i0, i1);
+    if (rc) return rc;
+    return launch_mark(h, &slot, 1);    // that kernel reads the slot's siconc: a later upload into the slot stays behind it
 }
 
 SITRK_API int sitrk_stage_submit(sitrk_t *h, int slot, int j0, int j1)
@@ -421,29 +506,19 @@ SITRK_API int sitrk_stage_submit(sitrk_t *h, int slot, int j0, int j1)
     NEED(h->slabs, "sitrk_stage_submit: call sitrk_alloc_records first");
     NEED(slot >= 0 && slot < h->nslots, "sitrk_stage_submit: slot out of range");
     NEED(h->stage_rows >= 0, "sitrk_stage_submit: nothing acquired");
-    NEED(j0 >= 0 && j1 <= h->Nj && j1 - j0 == h->stage_rows, "sitrk_stage_submit: rows [j0,j1) do not match the acquired buffer");
-    HIPCHK(hipSetDevice(h->device));
-    const int b = h->stage_next;
-    const size_t n = (size_t)h->Nj * h->Ni, es = elem_size(h->dtype);
-    const size_t off = (size_t)j0 * h->Ni * es, nb = (size_t)(j1 - j0) * h->Ni * es;
-    char *d = slab_of(h, slot);
-    const char *src = (const char *)h->stage[b];
-    // the copy may not overtake kernels that still read the slot; nothing else on the compute stream holds it back
-    if (h->slot_used_seq[slot] >= 0) HIPCHK(hipStreamWaitEvent(h->copy_stream, h->launch_ev[h->slot_used_seq[slot] % sitrk_ctx::kLaunchRing], 0));
-    HIPCHK(hipMemcpyAsync(d + off, src, nb, hipMemcpyHostToDevice, h->copy_stream));
-    HIPCHK(hipMemcpyAsync(d + n * es + off, src + nb, nb, hipMemcpyHostToDevice, h->copy_stream));
-    HIPCHK(hipMemcpyAsync(d + 2 * n * es + off, src + 2 * nb, nb, hipMemcpyHostToDevice, h->copy_stream));
-    HIPCHK(hipEventRecord(h->stage_done[b], h->copy_stream));
-    if (!h->slot_ready[slot]) HIPCHK(hipEventCreateWithFlags(&h->slot_ready[slot], hipEventDisableTiming));
-    HIPCHK(hipEventRecord(h->slot_ready[slot], h->copy_stream));
-    h->slot_pending[slot] = 1;
-    h->stage_rows = -1;
-    h->stage_next = (b + 1) % sitrk_ctx::kStage;
-    h->slot_row_lo[slot] = j0; h->slot_row_hi[slot] = j1;
-    // the Survive bytes these rows determine, on the compute stream behind the upload
-    int rc = derive_mask_rows(h, slot, j0, j1, j0, j1);
-    if (rc) return rc;
-    return launch_mark(h, &slot, 1);    // that kernel reads the slot's siconc: a later upload into the slot stays behind it
+    NEED(j0 >= 0 && j1 <= h->Nj && j1 - j0 == h->stage_rows && h->stage_cols == h->Ni, "sitrk_stage_submit: rows [j0,j1) do not match the acquired buffer");
+    return stage_submit_box(h, slot, j0, j1, 0, h->Ni);
+}
+
+SITRK_API int sitrk_stage_submit_box(sitrk_t *h, int slot, int j0, int j1, int i0, int i1)
+{
+    NEED(h, "null handle");
+    NEED(h->slabs, "sitrk_stage_submit_box: call sitrk_alloc_records first");
+    NEED(slot >= 0 && slot < h->nslots, "sitrk_stage_submit_box: slot out of range");
+    NEED(h->stage_rows >= 0, "sitrk_stage_submit_box: nothing acquired");
+    NEED(j0 >= 0 && j1 <= h->Nj && j1 - j0 == h->stage_rows && i0 >= 0 && i1 <= h->Ni && i1 - i0 == h->stage_cols,
+         "sitrk_stage_submit_box: the box does not match the acquired buffer");
+    return stage_submit_box(h, slot, j0, j1, i0, i1);
 }
 
 SITRK_API int sitrk_stage_release(sitrk_t *h)
@@ -453,12 +528,13 @@ SITRK_API int sitrk_stage_release(sitrk_t *h)
     return SITRK_OK;
 }
 
-static int push_rows(sitrk_ctx *h, int slot, int j0, int j1, const void *u, const void *v, const void *sic)
+// host arrays holding exactly the box (densely packed, (j1-j0) x (i1-i0)) -> staging -> slot
+static int push_box(sitrk_ctx *h, int slot, int j0, int j1, int i0, int i1, const void *u, const void *v, const void *sic)
 {
     void *su, *sv, *ss;
-    int rc = sitrk_stage_acquire(h, j1 - j0, &su, &sv, &ss);
+    int rc = stage_acquire_box(h, j1 - j0, i1 - i0, &su, &sv, &ss);
     if (rc) return rc;
-    const size_t nb = (size_t)(j1 - j0) * h->Ni * elem_size(h->dtype);
+    const size_t nb = (size_t)(j1 - j0) * (i1 - i0) * elem_size(h->dtype);
     // from here on the caller's buffers are its own again.  One thread copies ~10 GB/s into pinned memory, a fifth of what
     // the PCIe link then moves: large records are copied by a few threads (201 MB at 4096^2: 20 ms -> 6 ms)
     const void *src[3] = {u, v, sic};
@@ -482,7 +558,7 @@ static int push_rows(sitrk_ctx *h, int slot, int j0, int j1, const void *u, cons
         for (int t = started; t < nthr - 1; t++) copy_part(t + 1);       // the parts nobody took
         for (int t = 0; t < started; t++) pool[t].join();
     }
-    return sitrk_stage_submit(h, slot, j0, j1);
+    return stage_submit_box(h, slot, j0, j1, i0, i1);
 }
 
 SITRK_API int sitrk_push_record(sitrk_t *h, int slot, const void *u, const void *v, const void *sic)
@@ -491,7 +567,25 @@ SITRK_API int sitrk_push_record(sitrk_t *h, int slot, const void *u, const void 
     NEED(h->slabs, "sitrk_push_record: call sitrk_alloc_records first");
     NEED(slot >= 0 && slot < h->nslots, "sitrk_push_record: slot out of range");
     NEED(u && v && sic, "sitrk_push_record: null field");
-    return push_rows(h, slot, 0, h->Nj, u, v, sic);
+    return push_box(h, slot, 0, h->Nj, 0, h->Ni, u, v, sic);
+}
+
+// rows and columns of the live buoys' host cells (one small kernel + one synchronisation of the compute stream)
+static int eval_buoy_box(sitrk_ctx *h)
+{
+    h->band_jmin = 1; h->band_jmax = 0; h->band_imin = 1; h->band_imax = 0; h->band_age = 0;
+    if (h->nP == 0) return SITRK_OK;
+    NEED(h->st[0].pos, "sitrk_buoy_rows: call sitrk_set_buoys first");
+    HIPCHK(hipSetDevice(h->device));
+    int init[4] = {0x7fffffff, -1, 0x7fffffff, -1}, res[4];
+    int *d = (int *)h->counter;                                     // 32 bytes
+    HIPCHK(hipMemcpyAsync(d, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(buoy_box_kernel, dim3(std::min(nblocks(h->nP), 2048u)), dim3(kBlock), 0, h->stream, h->nP, h->st[h->cur].cell, d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(res, d, sizeof(res), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (res[1] >= 0) { h->band_jmin = res[0]; h->band_jmax = res[1]; h->band_imin = res[2]; h->band_imax = res[3]; }
+    return SITRK_OK;
 }
 
 SITRK_API int sitrk_buoy_rows(sitrk_t *h, int32_t *jmin, int32_t *jmax)
@@ -499,19 +593,20 @@ SITRK_API int sitrk_buoy_rows(sitrk_t *h, int32_t *jmin, int32_t *jmax)
     NEED(h, "null handle");
     NEED(jmin && jmax, "sitrk_buoy_rows: null output");
     *jmin = 1; *jmax = 0;
-    h->band_jmin = 1; h->band_jmax = 0; h->band_age = 0;
-    if (h->nP == 0) return SITRK_OK;
-    NEED(h->st[0].pos, "sitrk_buoy_rows: call sitrk_set_buoys first");
-    HIPCHK(hipSetDevice(h->device));
-    int init[2] = {0x7fffffff, -1}, res[2];
-    int *d = (int *)h->counter;                                     // 8 bytes
-    HIPCHK(hipMemcpyAsync(d, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(buoy_rows_kernel, dim3(std::min(nblocks(h->nP), 2048u)), dim3(kBlock), 0, h->stream, h->nP, h->st[h->cur].cell, d);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(res, d, sizeof(res), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    if (res[1] >= 0) { *jmin = res[0]; *jmax = res[1]; }
-    h->band_jmin = *jmin; h->band_jmax = *jmax;
+    int rc = eval_buoy_box(h);
+    if (rc) return rc;
+    *jmin = h->band_jmin; *jmax = h->band_jmax;
+    return SITRK_OK;
+}
+
+SITRK_API int sitrk_buoy_box(sitrk_t *h, int32_t *jmin, int32_t *jmax, int32_t *imin, int32_t *imax)
+{
+    NEED(h, "null handle");
+    NEED(jmin && jmax && imin && imax, "sitrk_buoy_box: null output");
+    *jmin = 1; *jmax = 0; *imin = 1; *imax = 0;
+    int rc = eval_buoy_box(h);
+    if (rc) return rc;
+    *jmin = h->band_jmin; *jmax = h->band_jmax; *imin = h->band_imin; *imax = h->band_imax;
     return SITRK_OK;
 }
 
@@ -521,9 +616,21 @@ SITRK_API int sitrk_push_record_rows(sitrk_t *h, int slot, int j0, int j1, const
     NEED(h->slabs, "sitrk_push_record_rows: call sitrk_alloc_records first");
     NEED(slot >= 0 && slot < h->nslots, "sitrk_push_record_rows: slot out of range");
     NEED(j0 >= 0 && j1 <= h->Nj && j0 <= j1, "sitrk_push_record_rows: rows out of range");
-    if (j0 == j1) { h->slot_row_lo[slot] = h->slot_row_hi[slot] = 0; return SITRK_OK; }
+    if (j0 == j1) { slot_holds(h, slot, 0, 0, 0, 0); return SITRK_OK; }
     NEED(u_rows && v_rows && sic_rows, "sitrk_push_record_rows: null field");
-    return push_rows(h, slot, j0, j1, u_rows, v_rows, sic_rows);
+    return push_box(h, slot, j0, j1, 0, h->Ni, u_rows, v_rows, sic_rows);
+}
+
+SITRK_API int sitrk_push_record_box(sitrk_t *h, int slot, int j0, int j1, int i0, int i1, const void *u_box, const void *v_box,
+                                    const void *sic_box)
+{
+    NEED(h, "null handle");
+    NEED(h->slabs, "sitrk_push_record_box: call sitrk_alloc_records first");
+    NEED(slot >= 0 && slot < h->nslots, "sitrk_push_record_box: slot out of range");
+    NEED(j0 >= 0 && j1 <= h->Nj && j0 <= j1 && i0 >= 0 && i1 <= h->Ni && i0 <= i1, "sitrk_push_record_box: box out of range");
+    if (j0 == j1 || i0 == i1) { slot_holds(h, slot, 0, 0, 0, 0); return SITRK_OK; }
+    NEED(u_box && v_box && sic_box, "sitrk_push_record_box: null field");
+    return push_box(h, slot, j0, j1, i0, i1, u_box, v_box, sic_box);
 }
 
 SITRK_API int sitrk_commit_record_rows(sitrk_t *h, int slot, int j0, int j1)
@@ -532,10 +639,46 @@ SITRK_API int sitrk_commit_record_rows(sitrk_t *h, int slot, int j0, int j1)
     NEED(h->slabs, "sitrk_commit_record_rows: call sitrk_alloc_records first");
     NEED(slot >= 0 && slot < h->nslots, "sitrk_commit_record_rows: slot out of range");
     NEED(j0 >= 0 && j1 <= h->Nj && j0 <= j1, "sitrk_commit_record_rows: rows out of range");
-    h->slot_row_lo[slot] = j0; h->slot_row_hi[slot] = j1;
-    if (j0 == j1) return SITRK_OK;
+    if (j0 == j1) { slot_holds(h, slot, 0, 0, 0, 0); return SITRK_OK; }
+    slot_holds(h, slot, j0, j1, 0, h->Ni);
     HIPCHK(hipSetDevice(h->device));
-    return derive_mask_rows(h, slot, j0, j1, j0, j1);
+    return derive_mask_box(h, slot, j0, j1, 0, h->Ni);
+}
+
+SITRK_API int sitrk_commit_record_box(sitrk_t *h, int slot, int j0, int j1, int i0, int i1)
+{
+    NEED(h, "null handle");
+    NEED(h->slabs, "sitrk_commit_record_box: call sitrk_alloc_records first");
+    NEED(slot >= 0 && slot < h->nslots, "sitrk_commit_record_box: slot out of range");
+    NEED(j0 >= 0 && j1 <= h->Nj && j0 <= j1 && i0 >= 0 && i1 <= h->Ni && i0 <= i1, "sitrk_commit_record_box: box out of range");
+    if (j0 == j1 || i0 == i1) { slot_holds(h, slot, 0, 0, 0, 0); return SITRK_OK; }
+    slot_holds(h, slot, j0, j1, i0, i1);
+    HIPCHK(hipSetDevice(h->device));
+    return derive_mask_box(h, slot, j0, j1, i0, i1);
+}
+
+SITRK_API int sitrk_commit_records_box(sitrk_t *h, int slot0, int nrec, int j0, int j1, int i0, int i1)
+{
+    NEED(h, "null handle");
+    NEED(h->slabs, "sitrk_commit_records_box: call sitrk_alloc_records first");
+    NEED(slot0 >= 0 && slot0 < h->nslots, "sitrk_commit_records_box: slot0 out of range");
+    NEED(nrec >= 0 && nrec <= h->nslots, "sitrk_commit_records_box: more records than slots");
+    NEED(j0 >= 0 && j1 <= h->Nj && j0 <= j1 && i0 >= 0 && i1 <= h->Ni && i0 <= i1, "sitrk_commit_records_box: box out of range");
+    HIPCHK(hipSetDevice(h->device));
+    const bool empty = (j0 == j1 || i0 == i1);
+    for (int k = 0; k < nrec; k += kSvMaxBatch) {
+        int slots[kSvMaxBatch];
+        const int nb = std::min(kSvMaxBatch, nrec - k);
+        for (int q = 0; q < nb; q++) {
+            slots[q] = (slot0 + k + q) % h->nslots;
+            if (empty) slot_holds(h, slots[q], 0, 0, 0, 0);
+            else slot_holds(h, slots[q], j0, j1, i0, i1);
+        }
+        if (empty) continue;
+        int rc = derive_mask_box_batch(h, slots, nb, j0, j1, i0, i1);
+        if (rc) return rc;
+    }
+    return SITRK_OK;
 }
 
 SITRK_API int sitrk_push_record_dev(sitrk_t *h, int slot, const void *slab_dev)
@@ -549,24 +692,30 @@ SITRK_API int sitrk_push_record_dev(sitrk_t *h, int slot, const void *slab_dev)
     int rc = slot_wait_upload(h, slot);
     if (rc) return rc;
     if (d != slab_dev) HIPCHK(hipMemcpyAsync(d, slab_dev, h->slab_bytes, hipMemcpyDeviceToDevice, h->stream));
-    h->slot_row_lo[slot] = 0; h->slot_row_hi[slot] = h->Nj;
+    slot_holds(h, slot, 0, h->Nj, 0, h->Ni);
     return derive_mask(h, slot);
 }
 
-// A slot that holds only a band of rows may be stepped with only while every live buoy is provably inside the band:
-// [jmin-2-age, jmax+3+age) with (jmin,jmax) from the last sitrk_buoy_rows() and age = records stepped since.
+// A slot that holds only a box of its record may be stepped with only while every live buoy is provably inside the box:
+// rows [jmin-2-age, jmax+3+age) and columns [imin-2-age, imax+3+age) with (jmin,jmax,imin,imax) from the last
+// sitrk_buoy_rows() / sitrk_buoy_box() and age = records stepped since.
 static int check_band(sitrk_ctx *h, int slot, int extra_age)
 {
-    const int lo = h->slot_row_lo[slot], hi = h->slot_row_hi[slot];
-    if (lo == 0 && hi == h->Nj) return SITRK_OK;
+    const int lo = h->slot_row_lo[slot], hi = h->slot_row_hi[slot], clo = h->slot_col_lo[slot], chi = h->slot_col_hi[slot];
+    if (lo == 0 && hi == h->Nj && clo == 0 && chi == h->Ni) return SITRK_OK;
     if (h->band_age < 0)
-        return fail(h, SITRK_EINVAL, "slot %d holds rows [%d,%d) only: call sitrk_buoy_rows() after sitrk_set_buoys() so that the band can be checked", slot, lo, hi);
+        return fail(h, SITRK_EINVAL, "slot %d holds rows [%d,%d) x columns [%d,%d) only: call sitrk_buoy_rows() / sitrk_buoy_box() after "
+                    "sitrk_set_buoys() so that the box can be checked", slot, lo, hi, clo, chi);
     if (h->band_jmin > h->band_jmax) return SITRK_OK;       // no live buoy
     const int age = h->band_age + extra_age;
     const int need_lo = std::max(0, h->band_jmin - 2 - age), need_hi = std::min(h->Nj, h->band_jmax + 3 + age);
     if (lo > need_lo || hi < need_hi)
         return fail(h, SITRK_EINVAL, "slot %d holds rows [%d,%d) but the buoys (rows %d..%d, %d records ago) can touch rows [%d,%d)",
                     slot, lo, hi, h->band_jmin, h->band_jmax, age, need_lo, need_hi);
+    const int cneed_lo = std::max(0, h->band_imin - 2 - age), cneed_hi = std::min(h->Ni, h->band_imax + 3 + age);
+    if (clo > cneed_lo || chi < cneed_hi)
+        return fail(h, SITRK_EINVAL, "slot %d holds columns [%d,%d) but the buoys (columns %d..%d, %d records ago) can touch columns [%d,%d)",
+                    slot, clo, chi, h->band_imin, h->band_imax, age, cneed_lo, cneed_hi);
     return SITRK_OK;
 }
 
@@ -1326,7 +1475,7 @@ SITRK_API int sitrk_survive_mask(sitrk_t *h, const double *sic, int8_t *mask)
     char *s = (char *)h->scratch;
     HIPCHK(hipMemcpyAsync(s, sic, cells * 8, hipMemcpyHostToDevice, h->stream));
     // the very kernel that derives a resident record's bytes (the packed neighbourhoods go to scratch and are dropped)
-    rc = launch_survive(h, true, s, (int8_t *)(s + b_s), (uint8_t *)(s + b_s + b_m), 0, h->Nj, 0, h->Nj);
+    rc = launch_survive(h, true, s, (int8_t *)(s + b_s), (uint8_t *)(s + b_s + b_m), 0, h->Nj, 0, h->Ni);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(mask, s + b_s, cells, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));

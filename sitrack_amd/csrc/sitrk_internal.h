@@ -42,6 +42,7 @@ struct sitrk_ctx {
     hipEvent_t stage_done[kStage] = {nullptr, nullptr};   // recorded on copy_stream behind the last DMA out of the buffer
     int stage_next = 0;                         // buffer the next acquire hands out
     int stage_rows = -1;                        // rows of the buffer handed out by acquire and not submitted yet (-1: none)
+    int stage_cols = 0;                         // ... and its columns (Ni for the row-band entry points)
 
     // grid
     int Nj = 0, Ni = 0;
@@ -84,9 +85,12 @@ struct sitrk_ctx {
     // rows [row_lo,row_hi) of the slot's u,v hold this record (whole record: 0..Nj); everything else is stale.
     // Survive bytes are valid for rows (row_lo, row_hi-1) and the domain rim.
     int slot_row_lo[4096] = {0}, slot_row_hi[4096] = {0};
-    // host rows of the live buoys at the last sitrk_buoy_rows(), and the records stepped since (a host cell moves
-    // at most one row per record): what a partly uploaded slot is checked against
+    // the same for the columns (box ingest, round 4): columns [col_lo,col_hi) of those rows hold this record
+    int slot_col_lo[4096] = {0}, slot_col_hi[4096] = {0};
+    // host rows and columns of the live buoys at the last sitrk_buoy_rows() / sitrk_buoy_box(), and the records stepped
+    // since (a host cell moves at most one row and one column per record): what a partly uploaded slot is checked against
     int band_jmin = 0, band_jmax = -1, band_age = -1;      // band_age < 0: not evaluated since sitrk_set_buoys
+    int band_imin = 0, band_imax = -1;
     // launch accounting (sitrk_launch_stats)
     long long n_fused_launches = 0, n_fused_records = 0, n_step_launches = 0;
 

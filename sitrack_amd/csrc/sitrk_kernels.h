@@ -13,6 +13,13 @@
 
 #pragma clang fp contract(off)
 
+// The ablation hooks below give WRONG results by design (timing only, profiles/r03s_*): they exist in diagnostic builds
+// (`make DIAG=1`) and nowhere else -- a stray -D must not ship a wrong tracker that still exports every symbol.
+#if (defined(SITRK_ABL_NOEDGE) || defined(SITRK_ABL_NODIAG) || defined(SITRK_ABL_VEL2) || defined(SITRK_ABL_NOK9) || \
+     defined(SITRK_NO_LAZY_HIT)) && !defined(SITRK_DIAG)
+#error "SITRK_ABL_* / SITRK_NO_LAZY_HIT are diagnostic ablations (wrong results): they need -DSITRK_DIAG (make DIAG=1)"
+#endif
+
 namespace sitrk {
 
 static constexpr int kBlock = 256;
@@ -89,6 +96,28 @@ __device__ __forceinline__ bool survive_kill(int jT, int iT, int Nj, int Ni, con
 // the sentinel "everything kills".
 // (round 2 did this in two passes, survive_mask_kernel + pack_kill9_kernel: 58 + 52 us per 4096^2 record.)
 // ---------------------------------------------------------------------------
+// Round 4: the same for a BOX of the record (rows x columns: what the buoys of this GPU can touch, sitrk_buoy_box).  Columns
+// follow the rows' rules: the kernel writes columns [c_lo, c_hi) (multiples of 4 on meshes with Ni % 4 == 0), of which the
+// siconc columns [cv_lo, cv_hi) are valid; a Survive byte is derived when its 3 x 3 stencil is valid in BOTH directions or
+// the cell belongs to the rim, a kill9 byte whose 3 x 3 byte neighbourhood is not all derivable gets the sentinel.
+struct SvBox {
+    int j_lo, j_hi, v_lo, v_hi;         // rows written / rows of siconc that are valid
+    int c_lo, c_hi, cv_lo, cv_hi;       // columns written / columns of siconc that are valid
+};
+// Several records in ONE launch (blockIdx.z): a fused launch of advect_run_kernel steps with up to 32 resident records, and their
+// Survive bytes are derived the same way -- one dispatch for the batch instead of one per record (a box of a 4096^2 record is 10 us
+// of memory traffic, of the order of a dependent dispatch itself).
+static constexpr int kSvMaxBatch = 32;
+struct SvBatch {
+    long long sic_stride, kill_stride;  // elements between two slots' siconc fields / bytes between their Survive arrays
+    int slot[kSvMaxBatch];
+};
+// Survive byte of column i derivable from the valid columns (rim columns always are: killed whatever the ice is)
+__device__ __forceinline__ bool sv_col_ok(int i, int Ni, int cv_lo, int cv_hi)
+{
+    return (i <= 1) | (i >= Ni - 2) | ((i - 1 >= cv_lo) & (i + 1 < cv_hi));
+}
+
 static constexpr int kSvTR = 32, kSvTC = 64;                   // cells per workgroup
 static constexpr int kSvSC = kSvTC + 4, kSvSR = kSvTR + 4;     // siconc / tmask tile: halo of 2 (two nested 3-row stencils)
 static constexpr int kSvKC = kSvTC + 2, kSvKR = kSvTR + 2;     // Survive bytes: halo of 1
@@ -96,14 +125,19 @@ static constexpr int kSvKP = 72;                               // their row pitc
 static constexpr int kSvBlock = 256;
 
 template <typename FT>
-__global__ __launch_bounds__(kSvBlock) void survive_kill9_kernel(int Nj, int Ni, int j_lo, int j_hi, int v_lo, int v_hi,
-                                                                const int8_t *__restrict__ tmask, const FT *__restrict__ sic,
-                                                                double rmin_conc, int8_t *__restrict__ kill, uint8_t *__restrict__ kill9)
+__global__ __launch_bounds__(kSvBlock) void survive_kill9_kernel(int Nj, int Ni, SvBox bx, SvBatch sb,
+                                                                const int8_t *__restrict__ tmask, const FT *__restrict__ sic0,
+                                                                double rmin_conc, int8_t *__restrict__ kill0, uint8_t *__restrict__ kill90)
 {
+    const FT *__restrict__ sic = sic0 + (size_t)sb.slot[blockIdx.z] * (size_t)sb.sic_stride;
+    int8_t *__restrict__ kill = kill0 + (size_t)sb.slot[blockIdx.z] * (size_t)sb.kill_stride;
+    uint8_t *__restrict__ kill9 = kill90 + (size_t)sb.slot[blockIdx.z] * (size_t)sb.kill_stride;
     __shared__ FT s_sic[kSvSR * kSvSC];
     __shared__ int8_t s_tm[kSvSR * kSvSC];
     __shared__ __attribute__((aligned(8))) uint8_t s_k[kSvKR * kSvKP];
-    const int jt0 = j_lo + (int)blockIdx.y * kSvTR, it0 = (int)blockIdx.x * kSvTC;
+    const int j_lo = bx.j_lo, j_hi = bx.j_hi, v_lo = bx.v_lo, v_hi = bx.v_hi;
+    const int jt0 = j_lo + (int)blockIdx.y * kSvTR, it0 = bx.c_lo + (int)blockIdx.x * kSvTC;
+    (void)j_lo;
     // ---- the tile's inputs, halo of 2, row-wise coalesced; outside the mesh: anything (such cells are rim or beyond)
     for (int t = threadIdx.x; t < kSvSR * kSvSC; t += kSvBlock) {
         const int r = t / kSvSC, c = t - r * kSvSC;
@@ -139,7 +173,7 @@ __global__ __launch_bounds__(kSvBlock) void survive_kill9_kernel(int Nj, int Ni,
     for (int g = threadIdx.x; g < kSvTR * (kSvTC / 4); g += kSvBlock) {
         const int r = g / (kSvTC / 4), c4 = (g - r * (kSvTC / 4)) * 4;
         const int j = jt0 + r, i0 = it0 + c4;
-        if (j >= j_hi || i0 >= Ni) continue;
+        if (j >= j_hi || i0 >= Ni || i0 >= bx.c_hi) continue;
         // byte rows j-1, j, j+1, columns i0-1 .. i0+4 (bytes 0..5 of each word; 6, 7 unused)
         // (two 4-byte aligned words each)
         const uint32_t *p0 = (const uint32_t *)&s_k[r * kSvKP + c4], *p1 = p0 + kSvKP / 4, *p2 = p1 + kSvKP / 4;
@@ -152,6 +186,12 @@ __global__ __launch_bounds__(kSvBlock) void survive_kill9_kernel(int Nj, int Ni,
             ok3 = ok3 & ((rr <= 1) | (rr >= Nj - 2) | ((rr - 1 >= v_lo) & (rr + 1 < v_hi)));
         }
         const bool wr_kill = (j <= 1) | (j >= Nj - 2) | ((j - 1 >= v_lo) & (j + 1 < v_hi));
+        // the same in the columns: bit q + 1 of dv6 = the Survive byte of column i0 + q (q = -1..4) can be derived
+        unsigned dv6 = 0;
+#pragma unroll
+        for (int q = -1; q <= 4; q++) dv6 |= (sv_col_ok(i0 + q, Ni, bx.cv_lo, bx.cv_hi) ? 1u : 0u) << (q + 1);
+        const unsigned okc = dv6 & (dv6 >> 1) & (dv6 >> 2);                           // columns q-1, q, q+1 all derivable
+        const unsigned wrm = wr_kill ? ((dv6 >> 1) & 0xfu) : 0u;
         unsigned w9 = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -160,17 +200,20 @@ __global__ __launch_bounds__(kSvBlock) void survive_kill9_kernel(int Nj, int Ni,
             unsigned w = (a & 1u) | ((a >> 7) & 2u) | ((a >> 14) & 4u) | ((b & 1u) << 3) | ((b >> 12) & 16u) |
                          ((c & 1u) << 5) | ((c >> 2) & 64u) | ((c >> 9) & 128u);
             const int i = i0 + q;
-            if (!(ok3 && i >= 1 && i <= Ni - 2)) w = 0xffu;
+            if (!(ok3 && ((okc >> q) & 1u) && i >= 1 && i <= Ni - 2)) w = 0xffu;
             w9 |= w << (8 * q);
         }
         const unsigned wk = (unsigned)(R1 >> 8);                                      // the strip's own four Survive bytes
         const size_t k = (size_t)j * Ni + i0;
-        if (vec) {
-            if (wr_kill) *(unsigned *)(kill + k) = wk;
+        if (vec && i0 + 4 <= bx.c_hi) {
+            if (wrm == 0xfu) *(unsigned *)(kill + k) = wk;
+            else
+                for (int q = 0; q < 4; q++)
+                    if ((wrm >> q) & 1u) kill[k + q] = (int8_t)((wk >> (8 * q)) & 0xffu);
             *(unsigned *)(kill9 + k) = w9;
         } else {
-            for (int q = 0; q < 4 && i0 + q < Ni; q++) {
-                if (wr_kill) kill[k + q] = (int8_t)((wk >> (8 * q)) & 0xffu);
+            for (int q = 0; q < 4 && i0 + q < Ni && i0 + q < bx.c_hi; q++) {
+                if ((wrm >> q) & 1u) kill[k + q] = (int8_t)((wk >> (8 * q)) & 0xffu);
                 kill9[k + q] = (uint8_t)((w9 >> (8 * q)) & 0xffu);
             }
         }
@@ -235,16 +278,30 @@ __device__ __forceinline__ double sv_shfl_dn(double v)
 }
 
 template <typename FT>
-__global__ __launch_bounds__(256) void survive_kill9_rows_kernel(int Nj, int Ni, int j_lo, int j_hi, int v_lo, int v_hi,
-                                                                const int8_t *__restrict__ tmask, const FT *__restrict__ sic,
-                                                                double rmin_conc, int8_t *__restrict__ kill, uint8_t *__restrict__ kill9)
+__global__ __launch_bounds__(256) void survive_kill9_rows_kernel(int Nj, int Ni, SvBox bx, SvBatch sb,
+                                                                const int8_t *__restrict__ tmask, const FT *__restrict__ sic0,
+                                                                double rmin_conc, int8_t *__restrict__ kill0, uint8_t *__restrict__ kill90)
 {
+    const FT *__restrict__ sic = sic0 + (size_t)sb.slot[blockIdx.z] * (size_t)sb.sic_stride;
+    int8_t *__restrict__ kill = kill0 + (size_t)sb.slot[blockIdx.z] * (size_t)sb.kill_stride;
+    uint8_t *__restrict__ kill9 = kill90 + (size_t)sb.slot[blockIdx.z] * (size_t)sb.kill_stride;
+    static_assert(sizeof(FT) == 4 || sizeof(FT) == 8, "records are binary32 or binary64");
+#if !defined(__gfx9__) && !defined(__GFX9__) && defined(__HIP_DEVICE_COMPILE__)
+#error "survive_kill9_rows_kernel uses the wave64 DPP row shifts of the gfx9 family (wave_shr:1 / wave_shl:1): build for gfx950"
+#endif
+    const int j_lo = bx.j_lo, j_hi = bx.j_hi, v_lo = bx.v_lo, v_hi = bx.v_hi;
     const int lane = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6);
     const int jr0 = j_lo + ((int)blockIdx.y * 4 + wv) * kSvRowsR;            // first output row of this wave
     if (jr0 >= j_hi) return;                                                  // (wave-uniform: no barrier in this kernel)
-    const int g0 = (int)blockIdx.x * kSvRowsCols + 4 * (lane - 1);           // first of the lane's four columns (lane 0: halo left)
+    const int g0 = bx.c_lo + (int)blockIdx.x * kSvRowsCols + 4 * (lane - 1); // first of the lane's four columns (lane 0: halo left); c_lo % 4 == 0
     const bool in_cols = g0 >= 0 && g0 < Ni;                                  // Ni % 4 == 0: a group is inside the mesh or outside, whole
-    const bool out_lane = lane >= 1 && lane <= 62 && in_cols;
+    const bool out_lane = lane >= 1 && lane <= 62 && in_cols && g0 < bx.c_hi;
+    // columns whose Survive byte can be derived from the valid columns: bit q + 1 = column g0 + q, q = -1..4
+    unsigned dv6 = 0;
+#pragma unroll
+    for (int q = -1; q <= 4; q++) dv6 |= (sv_col_ok(g0 + q, Ni, bx.cv_lo, bx.cv_hi) ? 1u : 0u) << (q + 1);
+    const unsigned okc = dv6 & (dv6 >> 1) & (dv6 >> 2);                       // packed byte of column q: columns q-1, q, q+1 all derivable
+    const unsigned dvc = (dv6 >> 1) & 0xfu;
     // columns of the domain rim (iT <= 1 or iT >= Ni-2, tracking.py:73), one bit per column of the group
     unsigned rimc = 0;
 #pragma unroll
@@ -321,12 +378,17 @@ __global__ __launch_bounds__(256) void survive_kill9_rows_kernel(int Nj, int Ni,
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     unsigned w = ((K0 >> q) & 7u) | (((K1 >> q) & 1u) << 3) | (((K1 >> (q + 2)) & 1u) << 4) | (((K2 >> q) & 7u) << 5);
-                    if (!(ok3 && ((intc >> q) & 1u))) w = 0xffu;
+                    if (!(ok3 && (((intc & okc) >> q) & 1u))) w = 0xffu;
                     w9 |= w << (8 * q);
                     wk |= ((K1 >> (q + 1)) & 1u) << (8 * q);
                 }
                 const size_t k = (size_t)jo * Ni + g0;
-                if (wr_kill) *(unsigned *)(kill + k) = wk;
+                if (wr_kill) {
+                    if (dvc == 0xfu) *(unsigned *)(kill + k) = wk;
+                    else                                                              // (a box's edge groups only)
+                        for (int q = 0; q < 4; q++)
+                            if ((dvc >> q) & 1u) kill[k + q] = (int8_t)((wk >> (8 * q)) & 0xffu);
+                }
                 *(unsigned *)(kill9 + k) = w9;
             }
             // ---- roll: row r becomes row r-1
@@ -340,22 +402,30 @@ __global__ __launch_bounds__(256) void survive_kill9_rows_kernel(int Nj, int Ni,
     }
 }
 
-// rows of the host cells of the buoys that are still alive: out[0] = min jT, out[1] = max jT
-__global__ __launch_bounds__(kBlock) void buoy_rows_kernel(int64_t n, const int32_t *__restrict__ cell, int *out)
+// rows and columns of the host cells of the buoys that are still alive: out = {min jT, max jT, min iT, max iT}
+__global__ __launch_bounds__(kBlock) void buoy_box_kernel(int64_t n, const int32_t *__restrict__ cell, int *out)
 {
-    __shared__ int smin[kBlock / 64], smax[kBlock / 64];
-    int lo = 0x7fffffff, hi = -1;
+    __shared__ int sm[4][kBlock / 64];
+    int lo = 0x7fffffff, hi = -1, ilo = 0x7fffffff, ihi = -1;
     for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < n; s += (int64_t)gridDim.x * kBlock) {
         const int32_t c = cell[s];
-        if (c >= 0) { const int j = cell_j(c); lo = min(lo, j); hi = max(hi, j); }
+        if (c >= 0) {
+            const int j = cell_j(c), i = cell_i(c);
+            lo = min(lo, j); hi = max(hi, j); ilo = min(ilo, i); ihi = max(ihi, i);
+        }
     }
-    for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_down(lo, off)); hi = max(hi, __shfl_down(hi, off)); }
-    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = lo; smax[threadIdx.x >> 6] = hi; }
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, __shfl_down(lo, off)); hi = max(hi, __shfl_down(hi, off));
+        ilo = min(ilo, __shfl_down(ilo, off)); ihi = max(ihi, __shfl_down(ihi, off));
+    }
+    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; sm[0][w] = lo; sm[1][w] = hi; sm[2][w] = ilo; sm[3][w] = ihi; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < kBlock / 64; w++) { lo = min(lo, smin[w]); hi = max(hi, smax[w]); }
+        for (int w = 1; w < kBlock / 64; w++) { lo = min(lo, sm[0][w]); hi = max(hi, sm[1][w]); ilo = min(ilo, sm[2][w]); ihi = max(ihi, sm[3][w]); }
         atomicMin(&out[0], lo);
         atomicMax(&out[1], hi);
+        atomicMin(&out[2], ilo);
+        atomicMax(&out[3], ihi);
     }
 }
 
@@ -1275,7 +1345,8 @@ __global__ void restore_state_kernel(int64_t n, BuoyState st, const int8_t *__re
     int32_t c = st.cell[s];
     if (!alive[o]) st.cell[s] = c | SITRK_DEAD_BIT;
     else if (cell_j(c) < 2 || cell_i(c) < 2) atomicOr(rim_alive, 1ull);      // a LIVE buoy in the two outermost rows/columns
-    st.kill_rec[s] = kill_rec[o];
+    // invariant the re-sort relies on (permute_state_kernel): alive <=> kill_rec == -1
+    st.kill_rec[s] = alive[o] ? -1 : kill_rec[o];
 }
 
 // ---------------------------------------------------------------------------

@@ -617,6 +617,119 @@ def test_row_band_ingest_equals_full_ingest(fdt):
         assert np.array_equal(res["band"][key], res["full"][key]), key
     assert not np.isnan(res["band"]["yx"]).any() and 0 < res["band"]["iAlive"].sum() < len(res["band"]["iAlive"])
 
+@pytest.mark.parametrize("fdt", [np.float32, np.float64])
+@pytest.mark.parametrize("Ni,tile", [(160, 0), (160, 1), (158, 0)])
+@pytest.mark.parametrize("mode", ["step", "run", "commit", "commit_run"])
+def test_box_ingest_equals_full_ingest(fdt, Ni, tile, mode):
+    """Round 4: only the BOX rows [jmin-2, jmax+3) x columns [imin-2, imax+3) of a record is uploaded (three strided DMAs out of
+    the pinned staging) and only its Survive bytes are derived; everything outside -- above, below, LEFT and RIGHT -- is poisoned
+    (NaN velocities, zero ice => Survive kills).  Trajectories must equal those of full uploads, record by record (`step`),
+    through fused launches whose boxes are widened by the records of a launch (`run`), and when the slab arrives in device
+    memory whole and only the box is committed (`commit`: what an RCCL broadcast or bench.py's fresh-records leg does).
+    Both Survive kernels (Ni = 158: rows not 16-byte aligned -> the LDS-tile form with unaligned box edges)."""
+    Nj = 200
+    grid = syn.make_grid(Nj, Ni, dkm=4.0, warp=1.0)
+    K, Nt = 6, 42
+    u, v, sic = syn.make_fields(grid, K=K, seed=21, umax=1.1, drift=0.7, ripple=0.1, dtype=fdt)   # fast: ~1 cell per record
+    tmask = grid["tmask"].copy(); tmask[88:92, 60:80] = 0
+    sic[:, 60:70, 70:95] = 0.03
+    _, yx = syn.make_buoys(grid, 30000, seed=12, frac=0.9)
+    yx = yx[(np.abs(yx[:, 0]) < 120.) & (np.abs(yx[:, 1]) < 100.)]      # a box in the middle of the mesh
+    res = {}
+    nfuse = 3
+    for ingest in ("full", "box"):
+        trk = make_tracker(grid, tmask, nfuse, field_dtype=fdt)
+        ctx = trk.ctx
+        ctx.set_tuning(survive_tile=tile, fuse=nfuse)
+        found, ji, _ = sit.FindContainingCell(yx, syn.nearest_t_plane(grid, yx), ctx=ctx)
+        trk.set_buoys(yx[found], ji[found])
+        poison = (np.full((Nj, Ni), np.nan, dtype=fdt), np.full((Nj, Ni), np.nan, dtype=fdt), np.zeros((Nj, Ni), dtype=fdt))
+        boxes = []
+
+        def deliver(slot, k, age):
+            if ingest == "full":
+                ctx.push_record(slot, u[k], v[k], sic[k])
+                return
+            j0, j1, i0, i1 = ctx.box(age)
+            boxes.append((j0, j1, i0, i1))
+            if mode in ("commit", "commit_run"):
+                # the whole slab is written in device memory, poisoned outside the box; only the box is committed
+                import torch
+                from sitrack_amd import distributed as sd
+                comp = [p_.copy() for p_ in poison]
+                for dst, src in zip(comp, (u[k], v[k], sic[k])):
+                    dst[j0:j1, i0:i1] = src[j0:j1, i0:i1]
+                ctx.sync()
+                sd.slot_tensor(ctx, slot).copy_(torch.from_numpy(sd.pack_slab(*comp, fdt)))
+                torch.cuda.synchronize()
+                if mode == "commit":
+                    ctx.commit_record_box(slot, j0, j1, i0, i1)
+                elif slot == nfuse - 1:                             # the launch's records in ONE Survive launch
+                    assert len(set(boxes[-nfuse:])) == 1
+                    ctx.commit_records_box(0, nfuse, j0, j1, i0, i1)
+            else:
+                ctx.push_record(slot, *poison)
+                ctx.push_record_box(slot, j0, j1, i0, i1, u[k][j0:j1, i0:i1], v[k][j0:j1, i0:i1], sic[k][j0:j1, i0:i1])
+
+        if mode in ("run", "commit_run"):
+            for b in range(Nt // nfuse):
+                for r in range(nfuse):
+                    deliver(r, (b * nfuse + r) % K, nfuse - 1)      # record r of a launch is stepped r records after the evaluation
+                ctx.run(0, b * nfuse, nfuse)
+        else:
+            for s in range(Nt):
+                deliver(0, s % K, 0)
+                trk.step(s, 0)
+        res[ingest] = trk.state()
+        if ingest == "box":
+            assert max((b[1] - b[0]) * (b[3] - b[2]) for b in boxes) < 0.6 * Nj * Ni and boxes[0] != boxes[-1]   # a real box, and it moved
+            assert all(b[2] % 4 == 0 and (b[3] % 4 == 0 or b[3] == Ni) for b in boxes)
+            jmin, jmax, imin, imax = ctx.buoy_box()
+            alive = res[ingest]["iAlive"] == 1
+            cells = res[ingest]["vJIt"][alive]
+            assert (jmin, jmax, imin, imax) == (cells[:, 0].min(), cells[:, 0].max(), cells[:, 1].min(), cells[:, 1].max())
+            assert ctx.launch_stats()["fused_launches"] == (Nt // nfuse if mode in ("run", "commit_run") else 0)
+        trk.close()
+    for key in ("yx", "vJIt", "iAlive", "kill_rec"):
+        assert np.array_equal(res["box"][key], res["full"][key]), key
+    assert not np.isnan(res["box"]["yx"]).any() and 0 < res["box"]["iAlive"].sum() < len(res["box"]["iAlive"])
+
+
+def test_survive_bytes_of_a_box_equal_those_of_the_whole_record(ctx):
+    """The Survive bytes a box commit derives are those of the whole-record pass wherever the box determines them, for boxes at
+    every alignment of their four edges, through the trajectories' own reader of the bytes: a cloud stepped once per box."""
+    Nj, Ni = 64, 96
+    grid = syn.make_grid(Nj, Ni, dkm=4.0, warp=0.0)
+    rng = np.random.default_rng(5)
+    tmask = (rng.random((Nj, Ni)) > 0.05).astype(np.int8)
+    sic = rng.choice([0.0, 0.08, 0.1, 0.12, 1.0], size=(Nj, Ni)).astype(np.float32)
+    u = np.full((Nj, Ni), 1.2, dtype=np.float32); v = np.full((Nj, Ni), -1.2, dtype=np.float32)     # every buoy crosses: 4.3 km per record
+    g2 = dict(grid); g2["tmask"] = tmask
+    for (j0, j1, i0, i1) in [(10, 40, 8, 60), (11, 41, 9, 61), (9, 50, 10, 62), (12, 39, 11, 63), (5, 60, 4, 92), (20, 30, 31, 49)]:
+        # buoys whose reach [j-2, j+3) x [i-2, i+3) lies inside the box
+        jj, ii = np.meshgrid(np.arange(j0 + 2, j1 - 2), np.arange(i0 + 2, i1 - 2), indexing="ij")
+        ji = np.stack([jj.ravel(), ii.ravel()], axis=1).astype(np.int32)
+        yx = np.stack([grid["Yt"][ji[:, 0], ji[:, 1]] + 0.3, grid["Xt"][ji[:, 0], ji[:, 1]] - 0.4], axis=1)
+        out = {}
+        for tile in (0, 1):
+            trk = make_tracker(grid, tmask, 1)
+            trk.ctx.set_tuning(survive_tile=tile)
+            trk.set_buoys(yx, ji)
+            assert trk.ctx.box() == (j0, j1, i0 - i0 % 4, min(Ni, -(-i1 // 4) * 4))
+            trk.ctx.push_record_box(0, j0, j1, i0, i1, u[j0:j1, i0:i1], v[j0:j1, i0:i1], sic[j0:j1, i0:i1])
+            trk.ctx.step(0, 0)                                   # exactly the box: fine
+            out[tile] = trk.state()
+            if out[tile]["iAlive"].any():
+                with pytest.raises(sit.SitrkError, match="can touch"):
+                    trk.ctx.step(0, 1)                               # one record later the box is one cell too narrow all around
+            trk.close()
+        ref = orc.Tracker(g2, yx, ji, nthreads=4)
+        ref.step(0, u.astype(np.float64), v.astype(np.float64), sic.astype(np.float64), want_out=False)
+        assert ref.ncross == len(yx) and 0 < ref.alive.sum() < len(yx)
+        for tile in (0, 1):
+            assert np.array_equal(out[tile]["iAlive"], ref.alive) and np.array_equal(out[tile]["vJIt"], ref.jiT), (j0, j1, i0, i1, tile)
+
+
 def test_async_ingest_ring_and_staging():
     """Library-owned ingest (include/sitrk.h: pinned staging, copy stream, events): records are pushed from TEMPORARY host
     arrays that are scribbled over right after the call, pushed two batches ahead of the launches that use them, read
@@ -717,6 +830,20 @@ def test_partly_uploaded_slot_is_checked_against_the_buoys_band():
         with pytest.raises(sit.SitrkError, match="can touch rows"):
             ctx.run(0, 0, 3)
         ctx.run(0, 0, 2)
+        # the same in the columns (round 4): rows wide enough, columns one short on the right
+        ctx.set_buoys(yx[found], ji[found])
+        jmin, jmax, imin, imax = ctx.buoy_box()
+        assert (imin, imax) == (int(ji[found][:, 1].min()), int(ji[found][:, 1].max()))
+        b = (jmin - 2, jmax + 3, imin - 2, imax + 2)
+        ctx.push_record_box(0, *b, u[0][b[0]:b[1], b[2]:b[3]], v[0][b[0]:b[1], b[2]:b[3]], sic[0][b[0]:b[1], b[2]:b[3]])
+        with pytest.raises(sit.SitrkError, match="can touch columns"):
+            ctx.step(0, 0)
+        b = (jmin - 2, jmax + 3, imin - 2, imax + 3)
+        ctx.push_record_box(0, *b, u[0][b[0]:b[1], b[2]:b[3]], v[0][b[0]:b[1], b[2]:b[3]], sic[0][b[0]:b[1], b[2]:b[3]])
+        ctx.step(0, 0)
+        with pytest.raises(sit.SitrkError, match="box out of range"):
+            z = np.zeros((Nj, Ni + 4), dtype=np.float32)
+            ctx.push_record_box(0, 0, Nj, -4, Ni, z, z, z)
     finally:
         trk.close()
 
