@@ -12,21 +12,29 @@ Workload: N = 1 -> BASELINE.json configs[2] (C3, the one the metric is quoted on
 (4 km), 1e7 random buoys in the central 60 %, 32 device-resident fp32 records (solid-body rotation + per-record drift,
 SURVEY.md 8d) cycled.  N > 1 -> configs[3] (C4): one process per GPU, each rank owns 1.25e7 buoys (1e8 over 8 GPUs; weak
 scaling), the record slabs are generated on rank 0 and broadcast over RCCL in place into every rank's resident slots;
-stepping needs no collective.  `c2` = configs[1] measured on the same GPU in the same process.
+stepping needs no collective.  `c2` = configs[1] measured on the same GPU in the same process.  `--warp W` shears the mesh
+(SURVEY 8d's optional curvilinear variant), `--config c5shape` is the NANUK4-shaped 566 x 492 curvilinear mesh with >= 1e7
+seeds kept by the product's own SeedInit under a synthetic land / ice mask (BASELINE configs[4]'s shape).
 
 Prints ONE JSON line (rank 0).
- * `roofline` of the fused kernel: bound "fp64_valu_issue"; achieved = VALU instructions per second (instructions per wave
-   and record from the committed rocprofv3 counters in profiles/traffic.json x waves x records really advanced, counted by
-   the library: sitrk_launch_stats) against 1024 SIMDs x 2.4 GHz / 4 cycles; `traffic` = measured fabric bytes per launch
-   (FETCH_SIZE x 2 + WRITE_SIZE of the same command, profiles/); `hbm` = the algorithmic-byte view (secondary: the kernel
-   is not HBM bound).  Algorithmic bytes follow SURVEY.md 8(d) -- 50 B of state per buoy + 56 B (48 B geometry + u,v) per
-   grid cell a step needs -- counting the cells the buoys' 2x2 stencils touch (the buoys fill the central 60 %; charging all
-   Nj*Ni cells would put the one-record kernel above the HBM peak; that figure is kept as survey_formula_*).
+ * `value`: the K resident records are cycled, so each record's Survive bytes (tracking.py:62-93 once per cell) are derived
+   once and reused K/records_resident times OUTSIDE the clock.  `fresh_records.value` = the same steps with every record
+   committed afresh (Survive re-derived over the box the buoys can touch, one launch per batch of records) INSIDE the clock.
+ * `roofline` of the fused kernel: bound "valu_issue+wave_chain"; achieved = VALU instructions per second (instructions per
+   wave and record from the committed rocprofv3 counters in profiles/traffic.json x waves x records really advanced, counted
+   by the library: sitrk_launch_stats) against a class-weighted issue ceiling (a model) and the uniform 4-cycle ceiling;
+   `lane_utilisation` = share of the issued lanes that do work; `stale` = the profiled binary is not the one that ran
+   (kernel fingerprints, tools/kernel_fingerprint.py) -- `frac` is dropped then.  `traffic` = measured fabric bytes per launch
+   (FETCH_SIZE x 2 + WRITE_SIZE of the same command, profiles/); `hbm` = the algorithmic-byte view.  Algorithmic bytes follow
+   SURVEY.md 8(d) -- 50 B of state per buoy + 56 B (48 B geometry + u,v) per grid cell a step needs.
  * `per_record_launch.roofline`: bound "hbm", algorithmic bytes of one record over the measured launch time.
  * `cpu_baseline`: the CPU oracle (oracle/sitrk_oracle.c, a port of the reference loop, OpenMP over buoys) timed on this
    box's host cores on a bounded sample of the same workload.
- * N > 1: `e2e_broadcast` = a short segment with ONE broadcast of every record's slab per step overlapped with the
-   stepping (RCCL broadcast and scatter + all-gather), next to the resident `value`.
+ * N = 1: `c4_shard` = C4's per-rank shard (1.25e7 buoys) on this one GPU -- the N = 1 point of the weak-scaling curve --
+   and `e2e_upload` = one record per step from host memory through the library's pinned staging (whole records and boxes).
+ * N > 1: `solo_same_shard` (rank 0 alone, the others idle) and `efficiency_vs_n1_same_shard`; `e2e_broadcast` = a short
+   segment with ONE broadcast of every record's slab per step overlapped with the stepping (RCCL broadcast and scatter +
+   all-gather), next to the resident `value`.
 """
 import argparse
 import json
@@ -153,6 +161,11 @@ CONFIGS = {
     # per-rank shard is C4's at every N, the total is C4's 1e8 at N = 8)
     "c4": (4096, 4096, 12_500_000, "C4: synthetic 4096x4096 C-grid, 1.25e7 buoys/GPU (1e8 over 8 GPUs), fp32 records, "
                                    "buoy-range partition + RCCL record broadcast"),
+    # BASELINE.json configs[4]'s SHAPE: the real NANUK4 mesh_mask is not in the container -- a curvilinear 566 x 492 mesh at
+    # 12.5 km (the NANUK4-shaped mesh of tests/test_gpu_configs.py), land + open water, 1.13e7 candidate seeds of which the
+    # product's SeedInit keeps those under the mask (>= 1e7)
+    "c5shape": (566, 492, 11_300_000, "C5 shape: NANUK4-shaped curvilinear 566x492 mesh (12.5 km, synthetic), >= 1e7 seeds kept by "
+                                      "SeedInit under a land / ice mask, hourly fp32 records"),
 }
 
 
@@ -163,6 +176,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default="auto", choices=["auto"] + sorted(CONFIGS),
                     help="auto = C3 (the headline configuration) on one GPU, C4's per-rank shard on several")
+    ap.add_argument("--warp", type=float, default=0.0,
+                    help="shear / stretch of the synthetic mesh (SURVEY 8d's curvilinear variant; 0 = axis-aligned squares, 1 = the "
+                         "warp of the parity tests); c5shape is always warped")
     ap.add_argument("--buoys", type=int, default=0, help="override the configuration's buoys per GPU (capacity runs; not the metric's workload)")
     ap.add_argument("--records", type=int, default=32, help="device-resident records, cycled (32 x 201 MB at 4096^2)")
     ap.add_argument("--resort", type=int, default=-1, help="re-sort buoys by cell every R steps (0 never, -1 default)")
@@ -173,14 +189,19 @@ def parse():
     ap.add_argument("--check", action="store_true", help="verify a subsample against the oracle after the run")
     ap.add_argument("--fuse", type=int, default=32,
                     help="resident records advanced per launch by sitrk_run (loop interchange; 1 = one launch per record)")
-    ap.add_argument("--e2e-full", action="store_true", help="e2e regime: upload whole records instead of the row band the buoys can touch")
+    ap.add_argument("--e2e-full", action="store_true", help="e2e regime: upload whole records instead of the box the buoys can touch")
+    ap.add_argument("--e2e-rows", action="store_true", help="e2e regime: upload row bands (round 1-3's form) instead of boxes")
     ap.add_argument("--e2e-library", action="store_true",
-                    help="e2e regime through the library's own pinned staging and copy stream (sitrk_stage_*), host fill included")
+                    help="e2e regime through the library's own pinned staging and copy stream (sitrk_push_record_box), host fill included")
     ap.add_argument("--only-fused", action="store_true",
-                    help="skip the two reference legs (one record per launch, 8 records per launch): profiling runs, so that every "
-                         "dispatch of advect_run_kernel in the trace is a launch of the timed configuration")
+                    help="skip every leg but the timed fused run (one record per launch, 8 records per launch, fresh records, C4 "
+                         "shard, e2e upload): profiling runs, so that every dispatch of advect_run_kernel in the trace is a launch of "
+                         "the timed configuration")
     ap.add_argument("--tune", default="", help="library tuning knobs for A/B runs, e.g. patch_kb=0,sort_tile=2080 (never change results)")
     ap.add_argument("--no-c2", action="store_true", help="skip the C2 (512x512, 1e5 buoys, 1000 steps) sub-measurement")
+    ap.add_argument("--no-fresh", action="store_true", help="skip the fresh-records leg (every record committed once, inside the clock)")
+    ap.add_argument("--no-c4-shard", action="store_true", help="N = 1: skip the C4 per-rank shard sub-measurement")
+    ap.add_argument("--no-e2e-upload", action="store_true", help="N = 1: skip the short end-to-end upload segment")
     ap.add_argument("--no-e2e-broadcast", action="store_true",
                     help="N > 1: skip the short end-to-end segment (one RCCL broadcast per record, overlapped with stepping)")
     ap.add_argument("--regime", default="resident", choices=["resident", "e2e"],
@@ -225,8 +246,9 @@ def cpu_baseline(grid, u, v, sic, yx, ji, target_s, uv_strategy):
                 break
         dt = time.perf_counter() - t0
         out[nthreads] = (nS * nrec / dt, nS, nrec)
+        cross = trk.ncross / float(nS * (nrec + 1))      # (the warm-up record counts too)
     rate, nS, nrec = out[cores]
-    return {"value": rate, "unit": "particle-steps/s", "cores": cores, "kind": "port",
+    return {"value": rate, "unit": "particle-steps/s", "cores": cores, "kind": "port", "crossing_rate": cross,
             "sample": "first %d buoys x %d records of the same workload, fp64 oracle with OpenMP over buoys" % (nS, nrec),
             "value_1core": out[1][0], "sample_1core": "%d buoys x %d records" % (out[1][1], out[1][2]),
             "reference_python": REFERENCE_PYTHON}
@@ -249,6 +271,71 @@ def cpu_baseline_check(ctx, grid, u, v, sic, yx, ji, nsteps, uv_strategy, nS=200
     assert np.array_equal(st["yx"][:nS], ref.pos) and np.array_equal(st["jiT"][:nS], ref.jiT)
     assert np.array_equal(st["alive"][:nS], ref.alive)
     print("check OK: first %d buoys bit-exact vs oracle after %d steps" % (nS, nsteps), file=sys.stderr)
+
+
+def make_workload(a, syn, ctx, rank, config):
+    """Grid, buoys (positions + host cells through the product's own locate) and the parameters of the synthetic fields for a
+    configuration.  Returns a dict; the grid is set on `ctx`."""
+    Nj, Ni, nP, label = CONFIGS[config]
+    if a.buoys > 0:
+        nP = a.buoys
+        label += " [--buoys %d override]" % nP
+    w = {"config": config, "Nj": Nj, "Ni": Ni, "label": label, "seeding": "uniform in the central 60 %"}
+    if config == "c5shape":
+        grid = syn.shift_grid(syn.make_grid(Nj, Ni, dkm=12.5, warp=1.0), -250., 150.)
+        tmask = grid["tmask"]
+        tmask[Nj // 3:Nj // 3 + Nj // 12, Ni // 2:Ni // 2 + Ni // 10] = 0            # an island
+        w["fields"] = dict(seed=77, umax=0.9, drift=0.3, ripple=0.1)
+        w["polynya"] = (slice(Nj // 2, Nj // 2 + Nj // 10), slice(Ni // 5, Ni // 5 + Ni // 6))   # open water: buoys that drift in die
+    else:
+        grid = syn.make_grid(Nj, Ni, dkm=4.0, warp=a.warp)
+        w["fields"] = dict(seed=2024, umax=0.3, drift=0.05)
+        if a.warp:
+            w["label"] = label = label.replace("synthetic ", "synthetic curvilinear (warp %g) " % a.warp)
+    w["grid"] = grid
+    ctx.set_grid(grid["Yf"], grid["Xf"], grid["Yu"], grid["Xu"], grid["Yv"], grid["Xv"], grid["tmask"])
+    ctx.set_params(3600., a.uv_strategy, 0.1)
+    w["yx"], w["ji"] = make_shard(a, syn, ctx, w, nP, 1234 + rank)
+    w["nP"] = len(w["yx"])
+    return w
+
+
+def make_shard(a, syn, ctx, w, nP, seed):
+    """nP buoys of workload `w` and their host cells"""
+    grid, Nj, Ni = w["grid"], w["Nj"], w["Ni"]
+    if w["config"] == "c5shape":
+        # the reference's own path: seeds (lat/lon + km, float32 like a seeding file) -> SeedInit (nearest T-point by Haversine,
+        # Survive, FindContainingCell: sitrack/tracking.py:98-178) on the device -> the kept ones are tracked
+        rng = np.random.default_rng(seed)
+        yx = np.stack([rng.uniform(grid["Yt"].min() + 30, grid["Yt"].max() - 30, nP), rng.uniform(grid["Xt"].min() + 30, grid["Xt"].max() - 30, nP)], axis=1)
+        yx = yx.astype(np.float32).astype(np.float64)
+        latlonT = ctx.cart2geo(np.stack([grid["Yt"].ravel(), grid["Xt"].ravel()], axis=1))
+        latT, lonT = latlonT[:, 0].reshape(Nj, Ni), np.mod(latlonT[:, 1], 360.).reshape(Nj, Ni)
+        sll = ctx.cart2geo(yx)
+        sll[:, 1] = np.mod(sll[:, 1], 360.)
+        sic0 = np.ones((Nj, Ni))
+        sic0[w["polynya"]] = 0.03
+        ji, keep, why = ctx.seed_init(sll, yx, latT, lonT, grid["resol"], sic0)
+        k = keep == 1
+        w["seeding"] = ("%d candidate seeds -> SeedInit kept %d (no nearest point %d, Survive %d, no containing cell %d)"
+                        % (nP, int(k.sum()), int((why == 1).sum()), int((why == 2).sum()), int((why == 3).sum())))
+        return np.ascontiguousarray(yx[k]), np.ascontiguousarray(ji[k]).astype(np.int32)
+    _, yx = syn.make_buoys(grid, nP, seed=seed, frac=0.6)
+    if grid["warp"] == 0.0:
+        ji = syn.regular_host_cell(grid, yx).astype(np.int32)
+        found, ji2 = ctx.find_cells(yx, ji)              # the product's own FindContainingCell also validates the analytic guess
+        assert found.all() and np.array_equal(ji2, ji), "host-cell seeding failed"
+        return yx, ji
+    found, ji = ctx.find_cells(yx, syn.nearest_t_index(grid, yx).astype(np.int32))
+    assert found.mean() > 0.999, "host-cell seeding failed on the warped mesh (%.4f found)" % found.mean()
+    return np.ascontiguousarray(yx[found]), np.ascontiguousarray(ji[found])
+
+
+def make_records(syn, w, K):
+    u, v, sic = syn.make_fields(w["grid"], K=K, **w["fields"])
+    if "polynya" in w:
+        sic[(slice(None),) + w["polynya"]] = 0.03
+    return u, v, sic
 
 
 def c2_subrun(sit, syn, dev, a, steps=1000, warmup=64):
@@ -287,6 +374,164 @@ def c2_subrun(sit, syn, dev, a, steps=1000, warmup=64):
                         "roofline fraction is claimed"}
     finally:
         ctx.close()
+
+
+def fresh_records_leg(ctx, K, fuse, s0, nsteps, sync):
+    """The timed run once more with NOTHING amortised over the record cycling: every record stepped with is committed afresh
+    right before the launch that uses it (sitrk_commit_records_box: its Survive bytes re-derived from its siconc, over the box the
+    buoys can touch, one Survive launch per fused launch), inside the clock.  What a run over distinct records pays per record
+    when the slabs arrive in device memory (an RCCL broadcast, a device-side producer); an upload over PCIe hides it (e2e_upload).
+    The box comes from sitrk_buoy_box_begin/_end: the evaluation is queued one launch ahead and collected while the next launch
+    runs, so the stream never drains; a box is therefore up to 2 x fuse - 1 records old and that many cells wider all around."""
+    sync()
+    ctx.launch_stats(reset=True)
+    jmin, jmax, imin, imax = ctx.buoy_box()
+    age = 0
+    pending = False
+    cells = []
+    ctx.timer_start()
+    t0 = time.perf_counter()
+    k = 0
+    while k < nsteps:
+        m = min(fuse, nsteps - k)
+        if pending:
+            jmin, jmax, imin, imax, age = ctx.buoy_box_end()        # queued before the previous launch: does not wait for it
+        box = ctx.box_of(jmin, jmax, imin, imax, age + m - 1)
+        ctx.buoy_box_begin()
+        pending = True
+        ctx.commit_records_box((s0 + k) % K, m, *box)
+        ctx.run((s0 + k) % K, s0 + k, m)
+        cells.append((box[1] - box[0]) * (box[3] - box[2]))
+        k += m
+    ms = ctx.timer_stop()
+    sync()
+    dt = time.perf_counter() - t0
+    if pending:
+        ctx.buoy_box_end()
+    st = ctx.launch_stats(reset=True)
+    # the Survive pass alone, same box, same batch size (its share of the time above)
+    box = ctx.box(fuse - 1)
+    m = min(fuse, K)
+    ctx.commit_records_box(0, m, *box)
+    ctx.sync()
+    ctx.timer_start()
+    for _ in range(5):
+        ctx.commit_records_box(0, m, *box)
+    sv_ms = ctx.timer_stop()
+    for slot in range(K):
+        ctx.commit_record(slot)                          # the resident legs that follow see whole records again
+    ctx.sync()
+    return {"dt": dt, "event_ms": ms, "stats": st, "box_cells_mean": float(np.mean(cells)), "survive_us_per_record": 1e3 * sv_ms / (5 * m),
+            "box": list(box)}
+
+
+def c4_shard_subrun(a, syn, ctx, w, K, fuse, s0, barrier):
+    """N = 1 only: BASELINE configs[3]'s per-rank shard (1.25e7 buoys, rank 0's seeds) on this GPU, same grid, same resident
+    records, same launch shape -- the N = 1 point that the N > 1 lines' per-GPU workload can be compared with."""
+    nP4 = CONFIGS["c4"][2]
+    yx, ji = make_shard(a, syn, ctx, dict(w, config="c4"), nP4, 1234)
+    ctx.set_buoys(yx, ji, sort=not a.no_sort)
+    ctx.set_tuning(fuse=fuse)
+    ctx.run(s0 % K, s0, a.warmup)
+    barrier()
+    ctx.launch_stats(reset=True)
+    ctx.timer_start()
+    t0 = time.perf_counter()
+    ctx.run((s0 + a.warmup) % K, s0 + a.warmup, a.steps)
+    ms = ctx.timer_stop()
+    barrier()
+    dt = time.perf_counter() - t0
+    st = ctx.launch_stats(reset=True)
+    return {"workload": CONFIGS["c4"][3], "buoys": len(yx), "steps": a.steps, "warmup": a.warmup, "value": len(yx) * a.steps / dt,
+            "unit": "particle-steps/s", "ms_per_step": 1e3 * dt / a.steps, "event_ms_per_step": ms / a.steps,
+            "launches": st["fused_launches"] + st["step_launches"], "alive_after": ctx.count_alive(),
+            "note": "what `bench.py --gpus N` gives every rank (rank 0's seeds): the same-shard N = 1 point of the weak-scaling curve"}
+
+
+def e2e_upload_segment(ctx, w, u, v, sic, K, s0, nsteps=48):
+    """N = 1 counterpart of `e2e_broadcast` (same keys per mode): every step's record comes from ordinary host arrays through
+    the library's pinned staging and copy stream (sitrk_push_record / sitrk_push_record_box: host gather by a few threads, then
+    DMA), double-buffered against the stepping -- whole records, and the box the buoys can touch.  PCIe bound; never `value`."""
+    Nj, Ni = w["Nj"], w["Ni"]
+    out = {"steps": nsteps, "slab_bytes": int(3 * Nj * Ni * 4), "note": "one record per step from host memory, overlapped with the stepping; not `value`"}
+    for mode in ("whole_record", "box"):
+        st = {"eval": -10**9, "box": (0, Nj, 0, Ni), "bytes": 0, "pending": False}
+
+        def deliver(sidx):
+            k = sidx % K
+            if mode == "whole_record":
+                ctx.push_record(sidx % 2, u[k], v[k], sic[k])
+                st["bytes"] += 3 * Nj * Ni * 4
+                return
+            j0, j1, i0, i1 = ctx.box_of(*st["box"], sidx - st["eval"])
+            ctx.push_record_box(sidx % 2, j0, j1, i0, i1, u[k][j0:j1, i0:i1], v[k][j0:j1, i0:i1], sic[k][j0:j1, i0:i1])
+            st["bytes"] += 3 * (j1 - j0) * (i1 - i0) * 4
+
+        def run(first, n):
+            for sidx in range(first, first + n):
+                if mode == "box":
+                    if st["pending"] and sidx - st["begin"] >= 8:
+                        r = ctx.buoy_box_end()                       # queued 8 records ago: no wait to speak of
+                        st["box"], st["eval"], st["pending"] = r[:4], st["begin"], False
+                    if not st["pending"] and sidx - st["eval"] >= 16:
+                        ctx.buoy_box_begin()
+                        st["pending"], st["begin"] = True, sidx
+                if sidx == first:
+                    deliver(sidx)
+                ctx.step(sidx % 2, sidx)
+                if sidx + 1 < first + n:
+                    deliver(sidx + 1)                  # its DMA waits for the step above only if it reuses that slot: it does not
+                if sidx % 16 == 0:
+                    _phase("e2e upload segment")
+
+        if mode == "box":
+            st["box"], st["eval"] = ctx.buoy_box(), s0
+        run(s0, 4)
+        ctx.sync()
+        st["bytes"] = 0
+        t0 = time.perf_counter()
+        run(s0 + 4, nsteps)
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        if st["pending"]:
+            ctx.buoy_box_end()
+        s0 += 4 + nsteps
+        out[mode] = {"ms_per_step": 1e3 * dt / nsteps, "slab_GBps_per_rank": st["bytes"] / nsteps / (dt / nsteps) / 1e9,
+                     "upload_bytes_per_step": st["bytes"] / nsteps, "particle_steps_per_s": ctx.nP * nsteps / dt}
+    return out, s0
+
+
+_HIP = []
+
+
+def _memcpy2d_h2d(dst, dpitch, src, spitch, width, height, stream):
+    """hipMemcpy2DAsync host -> device on `stream` (the HIP runtime the process already runs on; torch has no strided async copy
+    that does not stage through a pageable temporary)"""
+    import ctypes as C
+    if not _HIP:
+        # the copy of the runtime this process already runs on (torch's bundled one, or the system's): never a second one
+        path = next((l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64.so" in l), "libamdhip64.so")
+        _HIP.append(C.CDLL(path))
+        _HIP[0].hipMemcpy2DAsync.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]
+        _HIP[0].hipMemcpy2DAsync.restype = C.c_int
+    rc = _HIP[0].hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, 1, stream)         # 1 = hipMemcpyHostToDevice
+    if rc:
+        raise RuntimeError("hipMemcpy2DAsync -> %d" % rc)
+
+
+def isa_fingerprint():
+    """fingerprint of the fused kernel in the library that is loaded (written by the build: tools/kernel_fingerprint.py)"""
+    try:
+        import sitrack_amd._lib as L
+        d = json.load(open(os.path.splitext(L.SO_PATH)[0] + ".isa.json"))
+        return d["kernels"]["advect_run_kernel<float,1,false>"]
+    except Exception:                                                # noqa: BLE001
+        return None
+
+
+def roofline_is_stale(profiled, shipped):
+    """the counter passes behind profiles/traffic.json describe the binary `profiled`; True unless it is the one that ran"""
+    return not (profiled and shipped and profiled.get("sha256") and profiled.get("sha256") == shipped.get("sha256"))
 
 
 def e2e_broadcast_segment(ctx, dist, torch, sd, rank, world, slabs_host, K, s0, Nj, Ni, nsteps=24):
@@ -415,26 +660,14 @@ def main():
 
     if a.config == "auto":
         a.config = "c3" if world == 1 else "c4"
-    Nj, Ni, nP, label = CONFIGS[a.config]
-    if a.buoys > 0:
-        nP = a.buoys
-        label += " [--buoys %d override]" % nP
     K = a.records
-    grid = syn.make_grid(Nj, Ni, dkm=4.0, warp=0.0)
-    # buoys: rank r owns the r-th contiguous range of the world*nP set
-    _, yx = syn.make_buoys(grid, nP, seed=1234 + rank, frac=0.6)
-    ji = syn.regular_host_cell(grid, yx).astype(np.int32)
-
     ctx = sit.Context(dev)
-    ctx.set_grid(grid["Yf"], grid["Xf"], grid["Yu"], grid["Xu"], grid["Yv"], grid["Xv"], grid["tmask"])
-    ctx.set_params(3600., a.uv_strategy, 0.1)
+    _phase("workload")
+    w = make_workload(a, syn, ctx, rank, a.config)
+    Nj, Ni, nP, label, grid, yx, ji = w["Nj"], w["Ni"], w["nP"], w["label"], w["grid"], w["yx"], w["ji"]
     ctx.alloc_records(K, np.float32)
     if a.tune:
         ctx.set_tuning(**{kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.tune.split(",")})
-
-    # host cells through the product's own FindContainingCell (also validates the analytic guess)
-    found, ji2 = ctx.find_cells(yx, ji)
-    assert found.all() and np.array_equal(ji2, ji), "host-cell seeding failed"
 
     from sitrack_amd import distributed as sd
 
@@ -443,7 +676,7 @@ def main():
     u = v = sic = None
     slabs_host = None
     if rank == 0:
-        u, v, sic = syn.make_fields(grid, K=K, seed=2024, umax=0.3, drift=0.05)
+        u, v, sic = make_records(syn, w, K)
         slabs_host = [sd.pack_slab(u[k], v[k], sic[k], np.float32) for k in range(K)]
     records_via = "host upload" if dist is None else ("RCCL broadcast from rank 0" if backend == "nccl" else backend + " broadcast from rank 0")
     _STATE["base"]["config"] = {"workload": label, "grid": [Nj, Ni], "buoys_per_gpu": nP, "buoys_total": nP * world, "regime": a.regime,
@@ -502,26 +735,50 @@ def main():
     per_record = None
     eight = None
     stats = None
+    fresh = None
+    solo = None
+    nrun = 0
     if a.regime == "resident":
         fuse = max(1, min(a.fuse, K, 32))               # a launch advances distinct resident records only
 
-        def timed_run(s0, nsteps, nfuse):
+        def timed_run(s0, nsteps, nfuse, sync=barrier):
             """nsteps records from step s0 at `nfuse` records per launch: (wall s, HIP-event ms, what was really launched)"""
             _phase("timed stepping, %d records per launch" % nfuse)
             ctx.set_tuning(fuse=nfuse)
-            barrier()
+            sync()
             ctx.launch_stats(reset=True)
             ctx.timer_start()
             t = time.perf_counter()
             ctx.run(s0 % K, s0, nsteps)
             ms = ctx.timer_stop()
-            barrier()
+            sync()
             return time.perf_counter() - t, ms, ctx.launch_stats(reset=True)
+
+        def local_sync():
+            ctx.sync()
+            torch.cuda.synchronize()
 
         ctx.set_tuning(fuse=fuse)
         ctx.run(0, 0, a.warmup)
-        dt, ev_ms, stats = timed_run(a.warmup, a.steps, fuse)
-        nrun = a.warmup + a.steps
+        nrun = a.warmup
+        if dist is not None and not a.only_fused:
+            # the same-shard N = 1 point, measured in THIS job: rank 0 steps alone while every other rank idles at the barrier
+            # (what follows is then the ratio of two runs of one binary on one node, not of two workloads)
+            _phase("solo leg (rank 0 alone)")
+            barrier()
+            if rank == 0:
+                solo = timed_run(nrun, a.steps, fuse, sync=local_sync)
+            barrier()
+            if rank != 0:
+                ctx.run(nrun % K, nrun, a.steps)       # every rank's buoys take the same steps (the check replays them)
+            nrun += a.steps
+        dt, ev_ms, stats = timed_run(nrun, a.steps, fuse)
+        nrun += a.steps
+        if fuse > 1 and not a.only_fused and not a.no_fresh:
+            # right behind the headline leg (the box the buoys can touch grows as the cloud rotates: same state, same launches)
+            _phase("fresh-records leg")
+            fresh = fresh_records_leg(ctx, K, fuse, nrun, a.steps, barrier)
+            nrun += a.steps
         if fuse > 1 and not a.only_fused:
             # for reference: the same K steps with one launch per record (the HBM-bound form of the kernel)
             dt1, ev1_ms, st1 = timed_run(nrun, a.steps, 1)
@@ -532,108 +789,102 @@ def main():
             eight = timed_run(nrun, a.steps, 8)[0]
             nrun += a.steps
         ctx.set_tuning(fuse=fuse)
-    elif a.e2e_library:
-        # end-to-end through the library's own ingest (sitrk_push_record_rows): every record is copied from ordinary host
-        # arrays into the library's pinned staging (the part a NetCDF reader plays in the driver, which reads into the
-        # staging directly) and travels on the library's copy stream while the previous record is stepped with.  One GPU only.
-        fuse = 1
-        assert world == 1 and K >= 2
-        band = {"eval": -10**9, "jmin": 0, "jmax": Nj - 1, "bytes": 0}
-
-        def deliver(sidx):
-            if a.e2e_full:
-                j0, j1 = 0, Nj
-            else:
-                age = sidx - band["eval"]
-                j0, j1 = max(0, band["jmin"] - 2 - age), min(Nj, band["jmax"] + 3 + age)
-            band["bytes"] += 3 * (j1 - j0) * Ni * 4
-            k = sidx % K                                         # host arrays -> the library's pinned staging -> copy stream
-            ctx.push_record_rows(sidx % 2, j0, j1, u[k][j0:j1], v[k][j0:j1], sic[k][j0:j1])
-
-        def run_e2e(s0, n):
-            for sidx in range(s0, s0 + n):
-                if not a.e2e_full and (sidx - band["eval"]) >= 32:
-                    band["jmin"], band["jmax"] = ctx.buoy_rows()
-                    band["eval"] = sidx
-                if sidx == s0:
-                    deliver(sidx)
-                ctx.step(sidx % 2, sidx)
-                if sidx + 1 < s0 + n:
-                    deliver(sidx + 1)              # its DMA waits for the step above only if it reuses that slot: it does not
-
-        run_e2e(0, a.warmup)
-        barrier()
-        ctx.timer_start()
-        t0 = time.perf_counter()
-        run_e2e(a.warmup, a.steps)
-        ev_ms = ctx.timer_stop()
-        barrier()
-        dt = time.perf_counter() - t0
-        e2e_bytes_per_step = band["bytes"] / float(a.warmup + a.steps)
     else:
+        # End-to-end: every step's record comes from host memory, double-buffered against the stepping (never `value`).
+        #   --e2e-library : ordinary host arrays -> the library's pinned staging (gathered by a few host threads: the part a
+        #                   NetCDF reader plays in the driver, which reads into the staging directly) -> its copy stream.  One GPU.
+        #   default       : pre-pinned torch tensors on a torch copy stream (rank 0), + one RCCL broadcast per record at N > 1.
+        # What travels: the BOX the buoys can touch (rows x columns, round 4; sitrk_buoy_box evaluated asynchronously every 16
+        # records), row bands (--e2e-rows, rounds 1-3), or whole records (--e2e-full, and always at N > 1: a broadcast).
         fuse = 1
-        # end-to-end: record s goes pinned host -> slot s%2 on a copy stream (rank 0), is broadcast, and is
-        # consumed by step s on the compute stream; delivery of record s+1 overlaps step s.
         assert K >= 2
         assert world == 1 or backend == "nccl", "the e2e regime broadcasts device slabs: needs RCCL"
-        comp, copy = torch.cuda.Stream(), torch.cuda.Stream()
-        ctx.set_stream(comp.cuda_stream)
-        slots = [sd.slot_tensor(ctx, 0), sd.slot_tensor(ctx, 1)]
-        pinned = [torch.from_numpy(x).pin_memory() for x in slabs_host] if rank == 0 else None
-        ready = [torch.cuda.Event(), torch.cuda.Event()]
-        free = [torch.cuda.Event(), torch.cuda.Event()]
+        assert not (a.e2e_library and world > 1)
+        whole = a.e2e_full or dist is not None
+        st = {"eval": 0, "box": (0, Nj - 1, 0, Ni - 1), "bytes": 0, "pending": False, "begin": 0, "shape": [None, None]}
+        if not a.e2e_library:
+            comp, copy = torch.cuda.Stream(), torch.cuda.Stream()
+            ctx.set_stream(comp.cuda_stream)
+            slots = [sd.slot_tensor(ctx, 0).view(3, Nj, Ni), sd.slot_tensor(ctx, 1).view(3, Nj, Ni)]
+            pinned = [torch.from_numpy(x).pin_memory().view(3, Nj, Ni) for x in slabs_host] if rank == 0 else None
+            ready = [torch.cuda.Event(), torch.cuda.Event()]
+            free = [torch.cuda.Event(), torch.cuda.Event()]
+            for e in free:
+                e.record(comp)
 
-        n_cells = Nj * Ni
-        band = {"eval": -10**9, "jmin": 0, "jmax": Nj - 1, "rows": [None, None], "bytes": 0}
+        def box_for(sidx):
+            if whole:
+                return 0, Nj, 0, Ni
+            j0, j1, i0, i1 = ctx.box_of(*st["box"], sidx - st["eval"])
+            return (j0, j1, 0, Ni) if a.e2e_rows else (j0, j1, i0, i1)
 
         def deliver(sidx):
-            b = sidx % 2
-            if a.e2e_full or dist is not None:
-                j0, j1 = 0, Nj
-            else:
-                # row-band ingest: rows the buoys can touch at record sidx, from the host rows sampled `age` records ago
-                age = sidx - band["eval"]
-                j0, j1 = max(0, band["jmin"] - 2 - age), min(Nj, band["jmax"] + 3 + age)
-            band["rows"][b] = (j0, j1)
-            band["bytes"] += 3 * (j1 - j0) * Ni * 4
+            b, k = sidx % 2, sidx % K
+            j0, j1, i0, i1 = box_for(sidx)
+            st["shape"][b] = (j0, j1, i0, i1)
+            st["bytes"] += 3 * (j1 - j0) * (i1 - i0) * 4
+            if a.e2e_library:
+                ctx.push_record_box(b, j0, j1, i0, i1, u[k][j0:j1, i0:i1], v[k][j0:j1, i0:i1], sic[k][j0:j1, i0:i1])
+                return
             with torch.cuda.stream(copy):
                 copy.wait_event(free[b])
                 if rank == 0:
-                    src = pinned[sidx % K]
-                    for f in range(3):
-                        lo_, hi_ = f * n_cells + j0 * Ni, f * n_cells + j1 * Ni
-                        slots[b][lo_:hi_].copy_(src[lo_:hi_], non_blocking=True)
+                    if i0 == 0 and i1 == Ni:
+                        for f in range(3):                           # three contiguous row ranges
+                            slots[b][f, j0:j1].copy_(pinned[k][f, j0:j1], non_blocking=True)
+                    else:
+                        for f in range(3):                           # strided DMA straight out of the pinned whole fields
+                            _memcpy2d_h2d(slots[b][f, j0, i0:].data_ptr(), Ni * 4, pinned[k][f, j0, i0:].data_ptr(), Ni * 4,
+                                          (i1 - i0) * 4, j1 - j0, copy.cuda_stream)
                 if dist is not None:
                     dist.broadcast(slots[b], src=0)
                 ready[b].record(copy)
 
         def run_e2e(s0, n):
             for sidx in range(s0, s0 + n):
-                if not (a.e2e_full or dist is not None) and (sidx - band["eval"]) >= 32:
-                    band["jmin"], band["jmax"] = ctx.buoy_rows()          # syncs the compute stream every 32 records
-                    band["eval"] = sidx
+                if not whole:
+                    if st["pending"] and sidx - st["begin"] >= 8:
+                        r = ctx.buoy_box_end()                       # queued 8 records ago: no wait to speak of
+                        st["box"], st["eval"], st["pending"] = r[:4], st["begin"], False
+                    if not st["pending"] and sidx - st["eval"] >= 16:
+                        ctx.buoy_box_begin()
+                        st["pending"], st["begin"] = True, sidx
                 if sidx == s0:
                     deliver(sidx)
-                if sidx + 1 < s0 + n:
-                    deliver(sidx + 1)
-                comp.wait_event(ready[sidx % 2])
-                ctx.commit_record_rows(sidx % 2, *band["rows"][sidx % 2])   # refresh the Survive bytes of the rows just written
-                ctx.step(sidx % 2, sidx)
-                free[sidx % 2].record(comp)
+                if a.e2e_library:
+                    ctx.step(sidx % 2, sidx)
+                    if sidx + 1 < s0 + n:
+                        deliver(sidx + 1)          # its DMA waits for the step above only if it reuses that slot: it does not
+                else:
+                    if sidx + 1 < s0 + n:
+                        deliver(sidx + 1)
+                    comp.wait_event(ready[sidx % 2])
+                    ctx.record_ptr(sidx % 2)                         # written in place: the Survive bytes of the box just written
+                    ctx.commit_record_box(sidx % 2, *st["shape"][sidx % 2])
+                    ctx.step(sidx % 2, sidx)
+                    free[sidx % 2].record(comp)
+                if sidx % 32 == 0:
+                    _phase("e2e stepping")                           # (keeps the no-progress watchdog of multi-rank runs quiet)
 
-        for e in free:
-            e.record(comp)
+        if not whole:
+            st["box"], st["eval"] = ctx.buoy_box(), 0
         run_e2e(0, a.warmup)
         barrier()
+        st["bytes"] = 0
         ctx.timer_start()
         t0 = time.perf_counter()
         run_e2e(a.warmup, a.steps)
         ev_ms = ctx.timer_stop()
         barrier()
         dt = time.perf_counter() - t0
-        ctx.set_stream(None)
-        e2e_bytes_per_step = band["bytes"] / float(a.warmup + a.steps)
+        if st["pending"]:
+            ctx.buoy_box_end()
+        if not a.e2e_library:
+            ctx.set_stream(None)
+        e2e_bytes_per_step = st["bytes"] / float(a.steps)
+        nrun = a.warmup + a.steps
     value_per_rank = None
+    fresh_dt = fresh["dt"] if fresh else 0.0
     if dist is not None:                                 # the slowest rank sets every reported time
         _phase("reductions")
         mine = torch.tensor([dt], dtype=torch.float64, device=red_dev)
@@ -642,13 +893,14 @@ def main():
         per = [float(nP) * a.steps / float(x[0]) for x in each]          # every rank's own particle-steps/s over the timed region
         value_per_rank = {"min": min(per), "max": max(per), "all": per}
         extra = [per_record[0], per_record[1]] if per_record is not None else [0.0, 0.0]
-        t = torch.tensor([dt, ev_ms] + extra + [eight or 0.0], dtype=torch.float64, device=red_dev)
+        t = torch.tensor([dt, ev_ms] + extra + [eight or 0.0, fresh_dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, ev_ms = float(t[0]), float(t[1])
         if per_record is not None:
             per_record = (float(t[2]), float(t[3]), per_record[2])
         if eight is not None:
             eight = float(t[4])
+        fresh_dt = float(t[5])
 
     _phase("count alive")
     nalive = ctx.count_alive()
@@ -658,8 +910,20 @@ def main():
         nalive = int(t[0])
 
     if a.check and rank == 0:
-        nchk = a.warmup + a.steps * (1 + (per_record is not None) + (eight is not None))
-        cpu_baseline_check(ctx, grid, u, v, sic, yx, ji, nchk, a.uv_strategy)
+        cpu_baseline_check(ctx, grid, u, v, sic, yx, ji, nrun, a.uv_strategy)
+
+    # ---- N = 1 extras on the same context, after everything `value` and the check need (they move the buoys on)
+    e2e_upload = None
+    c4_shard = None
+    plain = world == 1 and dist is None and a.regime == "resident" and not a.only_fused
+    if plain and not a.no_e2e_upload and K >= 2:
+        _phase("e2e upload segment")
+        e2e_upload, nrun = e2e_upload_segment(ctx, w, u, v, sic, K, nrun)
+        for k in (0, 1):
+            ctx.push_record(k, u[k], v[k], sic[k])           # the two slots the segment used hold whole records again
+    if plain and a.config == "c3" and a.buoys == 0 and not a.no_c4_shard:
+        _phase("c4 shard sub-run")
+        c4_shard = c4_shard_subrun(a, syn, ctx, w, K, fuse, nrun, barrier)
 
     def measured_copy_GBps():
         """practical HBM ceiling of this GPU, measured now: a device-to-device copy of 1 GiB (read + write bytes / time)"""
@@ -688,7 +952,7 @@ def main():
 
         def _segment():
             torch.cuda.set_device(dev)
-            box["out"] = e2e_broadcast_segment(ctx, dist, torch, sd, rank, world, slabs_host, K, a.warmup + a.steps * 3, Nj, Ni)
+            box["out"] = e2e_broadcast_segment(ctx, dist, torch, sd, rank, world, slabs_host, K, nrun, Nj, Ni)
 
         _phase("e2e broadcast segment")
         th = threading.Thread(target=_segment, daemon=True)
@@ -758,18 +1022,39 @@ def main():
             cpi = 4.0 * w64 + 2.0 * (1.0 - w64) if w64 is not None else 4.0
             peak = 1024 * 2.4 / cpi
             held = prof_fused.get("sclk_ghz")
-            out = {"bound": "fp64_valu_issue", "unit": "Ginst/s", "peak": peak,
+            shipped, profiled = isa_fingerprint(), prof_fused.get("isa")
+            stale = roofline_is_stale(profiled, shipped)
+            out = {"bound": "valu_issue+wave_chain", "unit": "Ginst/s", "peak": peak,
+                   "bound_note": "the loop sits where two bounds meet (DESIGN 3.2 item 35): the vector pipe is ~88 % busy AND seven resident "
+                                 "waves each need ~6 500 cycles per record (dependent chain); removing 38 % of the vector instructions "
+                                 "bought 6 % -- `frac` is the share of an instruction-COUNT ceiling, not the distance to a hard limit",
                    "kernel": "advect_run_kernel", "launches": nl, "records_advanced": nr, "one_record_launches": ns,
                    "records_per_launch": rpl, "avg_launch_ms": launch_ms, "waves_per_launch": nwaves,
                    "valu_inst_per_wave_record": ipwr, "valu_inst_source": ipwr_src,
                    "valu64_class_share": w64, "cycles_per_valu_inst": cpi,
-                   "peak_note": "1024 SIMDs x 2.4 GHz / (4 cycles x share of 64-bit-class VALU instructions + 2 cycles x the rest)",
-                   "peak_uniform_4_cycles": VALU_PEAK_GINST}
+                   "peak_note": "a MODEL: 1024 SIMDs x 2.4 GHz / (4 cycles x share of 64-bit-class VALU instructions + %s cycles x the rest); "
+                                "peak_uniform_4_cycles prices every wave64 VALU instruction at 4 cycles (%s)"
+                                % ("2", prof.get("valu_issue_microbench", {}).get("summary", "32-bit issue cost not pinned by a microbenchmark yet")),
+                   "peak_uniform_4_cycles": VALU_PEAK_GINST,
+                   "stale": stale, "isa_shipped": shipped, "isa_profiled": profiled}
+            # share of the issued lanes that do work: the main path runs with all 64 lanes, the crossing path -- every wave, every
+            # record -- with the lanes whose buoy left its cell (p_cross of them)
+            main_i, cross_i = prof_fused.get("valu_main_path_per_wave_record"), prof_fused.get("valu_crossing_path_per_wave_record")
+            if main_i and cross_i and p_cross is not None:
+                out["lane_utilisation"] = (main_i + cross_i * p_cross) / (main_i + cross_i)
+                out["lane_utilisation_note"] = ("(%.0f main-path instructions x 64 lanes + %.0f crossing-path instructions x %.1f lanes) / "
+                                                "(all instructions x 64): %.3f of the buoy-records leave their cell (%s)"
+                                                % (main_i, cross_i, 64 * p_cross, p_cross, p_cross_src))
             if ipwr:
                 ach = ipwr * nwaves / rec_s / 1e9
-                out.update({"achieved": ach, "frac": ach / peak, "frac_uniform_4_cycles": ach / VALU_PEAK_GINST,
+                out.update({"achieved": ach, "frac": None if stale else ach / peak,
+                            "frac_uniform_4_cycles": None if stale else ach / VALU_PEAK_GINST,
                             "clock_held_ghz": held, "clock_held_source": prof_fused.get("source"),
-                            "frac_at_held_clock": (ach / (1024 * held / cpi)) if held else None})
+                            "frac_at_held_clock": (ach / (1024 * held / cpi)) if (held and not stale) else None})
+                if stale:
+                    out["stale_note"] = ("the rocprofv3 counter passes behind valu_inst_per_wave_record / valu64_class_share / clock_held_ghz "
+                                         "(profiles/traffic.json) describe another build of advect_run_kernel than the one that ran: frac is "
+                                         "withheld; `achieved` uses the OLD instruction count and is indicative only")
             else:
                 out.update({"achieved": None, "frac": None})
             tr = prof_fused.get("hbm_bytes_per_launch") if a.buoys == 0 else None
@@ -789,16 +1074,27 @@ def main():
                                   "for all its records (loop interchange), and only the cells that host buoys (cells_needed) are read"}
             return out
 
+        # crossing rate of THIS workload (share of the buoy-records that leave their cell): counted by the CPU oracle on its
+        # baseline sample when that leg runs, else the figure stored with the profile
+        cpu_base = None
+        if world == 1 and not a.no_cpu_baseline:
+            _phase("cpu baseline")
+            cpu_base = cpu_baseline(grid, u, v, sic, yx, ji, a.cpu_seconds, a.uv_strategy)
+        p_cross, p_cross_src = prof_fused.get("crossing_rate"), "profiles/traffic.json"
+        if cpu_base is not None and cpu_base.get("crossing_rate") is not None:
+            p_cross, p_cross_src = cpu_base["crossing_rate"], "counted by the oracle on the cpu_baseline sample of this run"
         if a.regime == "resident" and fuse > 1 and stats["fused_launches"] > 0:
             roof = roofline_fused(ev_ms, stats)
         else:
             roof = roofline_step(1e3 * step_s)
+        amort = (a.steps + a.warmup) / float(K) if a.regime == "resident" else None
         line = {
             "metric": "particle-steps/s", "value": total / dt, "unit": "particle-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": label, "grid": [Nj, Ni], "buoys_per_gpu": nP, "buoys_total": nP * world,
+                       "warp": float(grid["warp"]), "seeding": w["seeding"],
                        "records_resident": K, "record_dtype": "f32", "uv_strategy": a.uv_strategy,
                        "sorted": not a.no_sort, "resort_every": 0 if a.no_sort else resort, "regime": a.regime,
                        "records_per_launch": fuse,
@@ -807,6 +1103,22 @@ def main():
                        "tune": a.tune or None},
             "roofline": roof,
         }
+        if a.regime == "resident":
+            line["note"] = ("the %d resident records are cycled: each record's Survive bytes (sitrack/tracking.py:62-93 once per cell) were "
+                            "derived once at ingest and reused ~%.1f times OUTSIDE the timed region; fresh_records.value has every record "
+                            "committed once, inside the clock" % (K, amort))
+        if fresh is not None:
+            fs = fresh["stats"]
+            line["fresh_records"] = {
+                "value": total / fresh_dt, "unit": "particle-steps/s", "ms_per_step": 1e3 * fresh_dt / a.steps,
+                "event_ms_per_step": fresh["event_ms"] / a.steps, "survive_us_per_record": fresh["survive_us_per_record"],
+                "survive_box_cells": fresh["box_cells_mean"], "survive_box_share_of_grid": fresh["box_cells_mean"] / float(Nj * Ni),
+                "launches": fs["fused_launches"], "records_advanced": fs["fused_records"] + fs["step_launches"],
+                "note": "same steps, same launches; before each launch its records are committed afresh (sitrk_commit_records_box: "
+                        "Survive re-derived from siconc over the box the buoys can touch, ONE Survive launch per fused launch; the box "
+                        "from sitrk_buoy_box_begin/_end queued one launch ahead), all inside the timed region"}
+            line["value_fresh_records"] = line["fresh_records"]["value"]
+            line["survive_us_per_record"] = fresh["survive_us_per_record"]
         if per_record is not None:
             dt1, ev1, st1 = per_record
             line["per_record_launch"] = {
@@ -820,16 +1132,28 @@ def main():
         if eight is not None:
             line["eight_records_per_launch"] = {"value": total / eight, "ms_per_step": 1e3 * eight / a.steps,
                                                 "note": "same kernel, 8 records per launch (SURVEY 8d keeps K = 8 records resident)"}
+        if solo is not None:
+            sdt, sms, sst = solo
+            line["solo_same_shard"] = {"value": float(nP) * a.steps / sdt, "ms_per_step": 1e3 * sdt / a.steps, "event_ms_per_step": sms / a.steps,
+                                       "launches": sst["fused_launches"] + sst["step_launches"],
+                                       "note": "rank 0 stepping its shard ALONE (every other rank idle at a barrier), same job, same binary: the "
+                                               "N = 1 point of this very workload"}
+            line["efficiency_vs_n1_same_shard"] = (total / dt) / (world * line["solo_same_shard"]["value"])
+        if c4_shard is not None:
+            line["c4_shard"] = c4_shard
+        if e2e_upload is not None:
+            line["e2e_upload"] = e2e_upload
         if rccl is not None:
             rccl["value_per_rank"] = value_per_rank
             line["rccl"] = rccl
         if e2e_bcast is not None:
             line["e2e_broadcast"] = e2e_bcast
         # (nothing below touches the GPU when the segment's thread is stuck inside a collective)
-        if world == 1 and not e2e_hung and a.regime == "resident" and a.config == "c3" and a.buoys == 0 and not a.no_c2:
+        if world == 1 and not e2e_hung and a.regime == "resident" and a.config == "c3" and a.buoys == 0 and not a.no_c2 and not a.warp:
+            _phase("c2 sub-run")
             line["c2"] = c2_subrun(sit, syn, dev, a)
-        if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(grid, u, v, sic, yx, ji, a.cpu_seconds, a.uv_strategy)
+        if cpu_base is not None:
+            line["cpu_baseline"] = cpu_base
         if rccl is not None and rccl.get("slab_checksum_ok") is False:
             line["degraded"] = "the resident slabs differ between ranks (slab_checksums)"
         _emit(line)

@@ -90,6 +90,7 @@ int sitrk_set_params(sitrk_t *h, double rdt, int uv_strategy, double rmin_conc);
  * order of the cell sort, tile-major tiles of tile_j x tile_i cells; "locate_bruteforce" (0/1):
  * SeedInit scans the whole grid per seed like the reference instead of the bounding-sphere search; "survive_tile" (0/1): derive a
  * record's Survive bytes with the LDS-tile kernel even where the register-rolling one applies (meshes with Ni % 4 == 0);
+ * "fill_threads" (1..16, default 8): host threads that copy a pushed record of 8 MB or more into the pinned staging;
  * "patch_kb" (0..63, default 16) / "patch_margin" (0..64, default 8): KB of LDS per workgroup that the fused kernel may fill with
  * the F-points of the cells around its buoys (0 = none: every geometry read goes to global memory), and the widest margin of
  * cells it takes around their bounding box; "xcd_group" (0..4096, default 16): runs of that many consecutive workgroups of the
@@ -148,8 +149,10 @@ int sitrk_commit_record_rows(sitrk_t *h, int slot, int j0, int j1);
  * (jT-2..jT+2, iT-2..iT+2); UpdtInd4NewCell moves a host cell by at most one row and one column per record.  With
  * (jmin,jmax,imin,imax) = sitrk_buoy_box() the next step can only touch the box rows [jmin-2, jmax+3) x columns
  * [imin-2, imax+3) of a record (36 % of the cells of BASELINE config 3, whose buoys fill the central 60 % x 60 %):
- *   sitrk_push_record_box     host arrays holding exactly the box, densely packed (j1-j0) x (i1-i0) -> slot (three strided
- *                             DMAs out of the library's pinned staging), + the Survive bytes the box determines
+ *   sitrk_push_record_box     host arrays -> slot (gathered into the library's pinned staging by a few threads, then three
+ *                             strided DMAs), + the Survive bytes the box determines.  u_box, v_box, sic_box address element
+ *                             (j0,i0); consecutive rows of the box are `ld` elements apart in the caller's arrays: ld = i1-i0
+ *                             for arrays that hold exactly the box, ld = Ni for pointers into whole (Nj,Ni) fields
  *   sitrk_stage_acquire_box / sitrk_stage_submit_box   the same for a reader that fills the pinned staging itself
  *                             (a NetCDF hyperslab read of si3_part_tracker.py:372-374 restricted to the box)
  *   sitrk_commit_record_box   the slab already sits in device memory (written through sitrk_record_ptr: an RCCL broadcast, a
@@ -159,7 +162,13 @@ int sitrk_commit_record_rows(sitrk_t *h, int slot, int j0, int j1);
  * sitrk_buoy_box() the slot must hold rows [jmin-2-age, jmax+3+age) and columns [imin-2-age, imax+3+age), else SITRK_EINVAL.
  * sitrk_buoy_rows() evaluates the columns too (a row band is a box of full width). */
 int sitrk_buoy_box(sitrk_t *h, int32_t *jmin, int32_t *jmax, int32_t *imin, int32_t *imax);
-int sitrk_push_record_box(sitrk_t *h, int slot, int j0, int j1, int i0, int i1, const void *u_box, const void *v_box, const void *sic_box);
+int sitrk_push_record_box(sitrk_t *h, int slot, int j0, int j1, int i0, int i1, const void *u_box, const void *v_box, const void *sic_box,
+                          int64_t ld);
+/* sitrk_buoy_box without stalling the stream: _begin queues the reduction behind the work already queued on the compute stream,
+ * _end waits for that point only (launches queued after the begin keep the GPU busy) and adopts the result -- the box then
+ * counts as evaluated at the begin; *age (optional) = records stepped since the begin.  One evaluation in flight at a time. */
+int sitrk_buoy_box_begin(sitrk_t *h);
+int sitrk_buoy_box_end(sitrk_t *h, int32_t *jmin, int32_t *jmax, int32_t *imin, int32_t *imax, int32_t *age);
 int sitrk_stage_acquire_box(sitrk_t *h, int nrows, int ncols, void **u, void **v, void **sic);
 int sitrk_stage_submit_box(sitrk_t *h, int slot, int j0, int j1, int i0, int i1);
 int sitrk_commit_record_box(sitrk_t *h, int slot, int j0, int j1, int i0, int i1);

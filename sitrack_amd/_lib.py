@@ -45,7 +45,9 @@ _SIGNATURES = {
     "sitrk_push_record_rows": (_int, [_vp, _int, _int, _int, _vp, _vp, _vp]),
     "sitrk_commit_record_rows": (_int, [_vp, _int, _int, _int]),
     "sitrk_buoy_box": (_int, [_vp] + [C.POINTER(C.c_int32)] * 4),
-    "sitrk_push_record_box": (_int, [_vp, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
+    "sitrk_push_record_box": (_int, [_vp, _int, _int, _int, _int, _int, _vp, _vp, _vp, _i64]),
+    "sitrk_buoy_box_begin": (_int, [_vp]),
+    "sitrk_buoy_box_end": (_int, [_vp] + [C.POINTER(C.c_int32)] * 5),
     "sitrk_stage_acquire_box": (_int, [_vp, _int, _int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "sitrk_stage_submit_box": (_int, [_vp, _int, _int, _int, _int, _int]),
     "sitrk_commit_record_box": (_int, [_vp, _int, _int, _int, _int, _int]),
@@ -318,11 +320,33 @@ class Context:
         return max(0, jmin - 2 - age), min(self.Nj, jmax + 3 + age), i0, i1
 
     def push_record_box(self, slot, j0, j1, i0, i1, u_box, v_box, sic_box):
+        """The box rows [j0,j1) x columns [i0,i1) of a record from three (j1-j0, i1-i0) arrays.  Views into whole fields
+        (`u[j0:j1, i0:i1]`: rows contiguous, one common row pitch) are handed over as they are -- the library gathers
+        them into its pinned staging -- anything else is made contiguous first."""
         shp = (j1 - j0, i1 - i0)
-        u = as_c(u_box, self.field_dtype, shp, "u box")
-        v = as_c(v_box, self.field_dtype, shp, "v box")
-        s = as_c(sic_box, self.field_dtype, shp, "sic box")
-        self._chk(self._L.sitrk_push_record_box(self._h, int(slot), int(j0), int(j1), int(i0), int(i1), _ptr(u), _ptr(v), _ptr(s)))
+        es = self.field_dtype.itemsize
+        arrs = [np.asarray(x) for x in (u_box, v_box, sic_box)]
+        for x, n in zip(arrs, ("u box", "v box", "sic box")):
+            if tuple(x.shape) != shp:
+                raise ValueError("%s: expected shape %s, got %s" % (n, shp, tuple(x.shape)))
+        pitched = all(x.dtype == self.field_dtype and x.ndim == 2 and x.strides[1] == es and x.strides[0] % es == 0
+                      and x.strides[0] >= shp[1] * es for x in arrs) and len({x.strides[0] for x in arrs}) == 1
+        if pitched and shp[0] > 0 and shp[1] > 0:
+            ld = arrs[0].strides[0] // es
+        else:
+            arrs = [as_c(x, self.field_dtype, shp) for x in arrs]
+            ld = shp[1]
+        self._chk(self._L.sitrk_push_record_box(self._h, int(slot), int(j0), int(j1), int(i0), int(i1), *[_ptr(x) for x in arrs], int(ld)))
+
+    def buoy_box_begin(self):
+        """queue the evaluation of buoy_box() on the compute stream without waiting for it (see sitrk_buoy_box_begin)"""
+        self._chk(self._L.sitrk_buoy_box_begin(self._h))
+
+    def buoy_box_end(self):
+        """(jmin, jmax, imin, imax, age): the box as it was when buoy_box_begin() was queued, and the records stepped since"""
+        v = [C.c_int32(0) for _ in range(5)]
+        self._chk(self._L.sitrk_buoy_box_end(self._h, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
 
     def commit_record_box(self, slot, j0, j1, i0, i1):
         self._chk(self._L.sitrk_commit_record_box(self._h, int(slot), int(j0), int(j1), int(i0), int(i1)))

@@ -113,7 +113,9 @@ SITRK_API int sitrk_create(sitrk_t **out, int device)
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     for (int b = 0; b < sitrk_ctx::kStage && e == hipSuccess; b++) e = hipEventCreateWithFlags(&c->stage_done[b], hipEventDisableTiming);
     for (int k = 0; k < sitrk_ctx::kLaunchRing && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->launch_ev[k], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMalloc((void **)&c->counter, 4 * sizeof(unsigned long long));     // reductions: up to 4 ints / one 64-bit count
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->box_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->box_host, 4 * sizeof(int), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->counter, 4 * sizeof(unsigned long long));     // reductions: 2 x 4 ints / one 64-bit count
     if (e != hipSuccess) {
         int rc = fail(h, SITRK_EHIP, "sitrk_create: %s", hipGetErrorString(e));
         (void)sitrk_destroy(c);                 // releases whatever was created before the failure
@@ -134,6 +136,8 @@ SITRK_API int sitrk_destroy(sitrk_t *h)
     free_records(h);
     dev_free(h->geo); dev_free(h->geoF); dev_free(h->orient); dev_free(h->tmask); dev_free(h->scratch); dev_free(h->counter);
     dev_free(h->stamps);
+    if (h->box_ev) (void)hipEventDestroy(h->box_ev);
+    if (h->box_host) (void)hipHostFree(h->box_host);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     for (int b = 0; b < sitrk_ctx::kStage; b++) if (h->stage_done[b]) (void)hipEventDestroy(h->stage_done[b]);
@@ -254,6 +258,11 @@ SITRK_API int sitrk_set_tuning(sitrk_t *h, const char *knob, int value)
         h->xcd_group = value;
         return SITRK_OK;
     }
+    else if (!strcmp(knob, "fill_threads")) {        // host threads that copy a pushed record into the pinned staging
+        if (value < 1 || value > 16) return fail(h, SITRK_EINVAL, "sitrk_set_tuning: fill_threads must be 1..16");
+        h->fill_threads = value;
+        return SITRK_OK;
+    }
     else if (!strcmp(knob, "patch_margin")) {
         if (value < 0 || value > 64) return fail(h, SITRK_EINVAL, "sitrk_set_tuning: patch_margin must be 0..64");
         h->patch_margin = value;
@@ -275,8 +284,8 @@ static inline size_t elem_size(int dtype) { return dtype == SITRK_F64 ? 8 : 4; }
 
 static void free_records(sitrk_ctx *h)
 {
-    dev_free(h->slabs); dev_free(h->kill); dev_free(h->kill9);
-    h->slabs = nullptr; h->kill = nullptr; h->kill9 = nullptr; h->nslots = 0;
+    dev_free(h->slabs); dev_free(h->kill9);
+    h->slabs = nullptr; h->kill9 = nullptr; h->nslots = 0;
     for (int b = 0; b < sitrk_ctx::kStage; b++) {
         if (h->stage[b]) (void)hipHostFree(h->stage[b]);
         h->stage[b] = nullptr;
@@ -304,11 +313,9 @@ SITRK_API int sitrk_alloc_records(sitrk_t *h, int nslots, int dtype)
     const size_t n = (size_t)h->Nj * h->Ni;
     h->slab_bytes = 3 * n * elem_size(dtype);
     HIPCHK(hipMalloc(&h->slabs, h->slab_bytes * nslots));
-    HIPCHK(hipMalloc((void **)&h->kill, n * nslots));
     HIPCHK(hipMalloc((void **)&h->kill9, n * nslots * sizeof(uint8_t)));
     // sentinels: a read outside the rows that were uploaded must be detectable, not silent garbage --
     // every Survive byte starts as "kill", every field value as NaN (0xff.. is a NaN in fp32 and fp64)
-    HIPCHK(hipMemsetAsync(h->kill, 1, n * nslots, h->stream));
     HIPCHK(hipMemsetAsync(h->kill9, 0xff, n * nslots * sizeof(uint8_t), h->stream));
     HIPCHK(hipMemsetAsync(h->slabs, 0xff, h->slab_bytes * nslots, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -396,7 +403,7 @@ static int derive_mask_box_batch(sitrk_ctx *h, const int *slots, int nb, int j0,
         if (rc) return rc;
     }
     if (!(j0 >= j1 || i0 >= i1)) {                      // (a slot that holds nothing: check_band refuses to step with it)
-        int rc = launch_survive(h, h->dtype == SITRK_F64, (const char *)h->slabs + 2 * n * es, h->kill, h->kill9, j0, j1, i0, i1,
+        int rc = launch_survive(h, h->dtype == SITRK_F64, (const char *)h->slabs + 2 * n * es, nullptr, h->kill9, j0, j1, i0, i1,
                                 slots, nb, (long long)(h->slab_bytes / es), (long long)n);
         if (rc) return rc;
     }
@@ -528,27 +535,59 @@ SITRK_API int sitrk_stage_release(sitrk_t *h)
     return SITRK_OK;
 }
 
-// host arrays holding exactly the box (densely packed, (j1-j0) x (i1-i0)) -> staging -> slot
-static int push_box(sitrk_ctx *h, int slot, int j0, int j1, int i0, int i1, const void *u, const void *v, const void *sic)
+// one row of a box into the (write-only, 16-byte aligned) pinned staging with non-temporal stores: a memcpy of a 10-KB row uses
+// ordinary stores, whose read-for-ownership doubles the traffic of the destination (measured on the box rows of C3, profiles/r04e_e2e.txt:
+// 4 threads 29 -> 36 GB/s, 8 threads 32 -> 47 GB/s; the PCIe link moves 55)
+static inline void copy_row_stream(char *d, const char *s, size_t n)
+{
+    typedef long long v2ll __attribute__((vector_size(16)));
+    typedef long long v2ll_u __attribute__((vector_size(16), aligned(1)));
+    size_t k = 0;
+    if (((uintptr_t)d & 15u) == 0) {
+        for (; k + 64 <= n; k += 64) {
+            const v2ll a = *(const v2ll_u *)(s + k), b = *(const v2ll_u *)(s + k + 16), c = *(const v2ll_u *)(s + k + 32),
+                       e = *(const v2ll_u *)(s + k + 48);
+            __builtin_nontemporal_store(a, (v2ll *)(d + k));
+            __builtin_nontemporal_store(b, (v2ll *)(d + k + 16));
+            __builtin_nontemporal_store(c, (v2ll *)(d + k + 32));
+            __builtin_nontemporal_store(e, (v2ll *)(d + k + 48));
+        }
+    }
+    if (k < n) memcpy(d + k, s + k, n - k);
+}
+
+// host arrays -> staging -> slot.  u, v, sic address element (j0,i0) of the box; consecutive rows of the box are `ld` elements
+// apart in the caller's arrays (ld = i1-i0: the arrays hold exactly the box, densely packed; ld = Ni: views into whole fields).
+static int push_box(sitrk_ctx *h, int slot, int j0, int j1, int i0, int i1, const void *u, const void *v, const void *sic, int64_t ld)
 {
     void *su, *sv, *ss;
     int rc = stage_acquire_box(h, j1 - j0, i1 - i0, &su, &sv, &ss);
     if (rc) return rc;
-    const size_t nb = (size_t)(j1 - j0) * (i1 - i0) * elem_size(h->dtype);
+    const size_t es = elem_size(h->dtype);
+    const size_t nr = (size_t)(j1 - j0), rowb = (size_t)(i1 - i0) * es, srcb = (size_t)ld * es;
+    const size_t nb = nr * rowb;
     // from here on the caller's buffers are its own again.  One thread copies ~10 GB/s into pinned memory, a fifth of what
     // the PCIe link then moves: large records are copied by a few threads (201 MB at 4096^2: 20 ms -> 6 ms)
     const void *src[3] = {u, v, sic};
     void *dst[3] = {su, sv, ss};
-    const int nthr = nb >= ((size_t)8 << 20) ? 4 : 1;
+    const int nthr = nb >= ((size_t)8 << 20) ? h->fill_threads : 1;
+    const bool dense = (srcb == rowb);
+    // thread t takes rows [t*part, (t+1)*part) of every field
+    const size_t part = (nr + nthr - 1) / nthr;
+    auto copy_part = [=](int t) {
+        const size_t r0 = (size_t)t * part, r1 = std::min(nr, r0 + part);
+        if (r0 >= r1) return;
+        for (int f = 0; f < 3; f++) {
+            if (dense) memcpy((char *)dst[f] + r0 * rowb, (const char *)src[f] + r0 * rowb, (r1 - r0) * rowb);
+            else
+                for (size_t r = r0; r < r1; r++) copy_row_stream((char *)dst[f] + r * rowb, (const char *)src[f] + r * srcb, rowb);
+        }
+        if (!dense) __atomic_thread_fence(__ATOMIC_SEQ_CST);      // (mfence: the streamed rows are globally visible before the DMA is queued)
+    };
     if (nthr == 1) {
-        for (int f = 0; f < 3; f++) memcpy(dst[f], src[f], nb);
+        copy_part(0);
     } else {
-        const size_t part = (nb + nthr - 1) / nthr;
-        auto copy_part = [=](int t) {
-            const size_t o = (size_t)t * part, n = o < nb ? std::min(part, nb - o) : 0;
-            for (int f = 0; f < 3 && n; f++) memcpy((char *)dst[f] + o, (const char *)src[f] + o, n);
-        };
-        std::thread pool[3];
+        std::thread pool[15];
         int started = 0;
         try {
             for (; started < nthr - 1; started++) pool[started] = std::thread(copy_part, started + 1);
@@ -567,24 +606,25 @@ SITRK_API int sitrk_push_record(sitrk_t *h, int slot, const void *u, const void 
     NEED(h->slabs, "sitrk_push_record: call sitrk_alloc_records first");
     NEED(slot >= 0 && slot < h->nslots, "sitrk_push_record: slot out of range");
     NEED(u && v && sic, "sitrk_push_record: null field");
-    return push_box(h, slot, 0, h->Nj, 0, h->Ni, u, v, sic);
+    return push_box(h, slot, 0, h->Nj, 0, h->Ni, u, v, sic, h->Ni);
 }
 
 // rows and columns of the live buoys' host cells (one small kernel + one synchronisation of the compute stream)
 static int eval_buoy_box(sitrk_ctx *h)
 {
+    h->box_pending = false;             // a synchronous evaluation supersedes one that was begun and not collected
     h->band_jmin = 1; h->band_jmax = 0; h->band_imin = 1; h->band_imax = 0; h->band_age = 0;
     if (h->nP == 0) return SITRK_OK;
     NEED(h->st[0].pos, "sitrk_buoy_rows: call sitrk_set_buoys first");
     HIPCHK(hipSetDevice(h->device));
-    int init[4] = {0x7fffffff, -1, 0x7fffffff, -1}, res[4];
-    int *d = (int *)h->counter;                                     // 32 bytes
-    HIPCHK(hipMemcpyAsync(d, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(buoy_box_kernel, dim3(std::min(nblocks(h->nP), 2048u)), dim3(kBlock), 0, h->stream, h->nP, h->st[h->cur].cell, d);
+    int res[4];
+    int *d = (int *)h->counter;                                     // first half of the 32-byte reduction scratch
+    HIPCHK(hipMemsetAsync(d, 0x80, 4 * sizeof(int), h->stream));    // four maxima start at -2139062144
+    hipLaunchKernelGGL(buoy_box_kernel, dim3(std::min(nblocks(h->nP, 4 * kBlock), 2048u)), dim3(kBlock), 0, h->stream, h->nP, h->st[h->cur].cell, d);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(res, d, sizeof(res), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    if (res[1] >= 0) { h->band_jmin = res[0]; h->band_jmax = res[1]; h->band_imin = res[2]; h->band_imax = res[3]; }
+    if (res[0] >= 0) { h->band_jmax = res[0]; h->band_jmin = -res[1]; h->band_imax = res[2]; h->band_imin = -res[3]; }
     return SITRK_OK;
 }
 
@@ -610,6 +650,45 @@ SITRK_API int sitrk_buoy_box(sitrk_t *h, int32_t *jmin, int32_t *jmax, int32_t *
     return SITRK_OK;
 }
 
+// The same without stalling the stream: _begin queues the reduction (and the copy of its result into pinned host memory) behind
+// the work already queued, _end waits for THAT point only -- launches queued after the begin keep the GPU busy meanwhile -- and
+// adopts the result: the box then counts as evaluated at the begin (records stepped since the begin are its age).
+SITRK_API int sitrk_buoy_box_begin(sitrk_t *h)
+{
+    NEED(h, "null handle");
+    NEED(!h->box_pending, "sitrk_buoy_box_begin: the evaluation begun before was not collected (sitrk_buoy_box_end)");
+    h->box_host[0] = -1; h->box_host[1] = 0; h->box_host[2] = -1; h->box_host[3] = 0;      // {max j, max -j, max i, max -i}: none alive
+    h->box_pending = true; h->box_pending_age = 0;
+    if (h->nP == 0) return SITRK_OK;
+    NEED(h->st[0].pos, "sitrk_buoy_box_begin: call sitrk_set_buoys first");
+    HIPCHK(hipSetDevice(h->device));
+    int *d = (int *)h->counter + 4;                                 // second half of the 32-byte reduction scratch
+    HIPCHK(hipMemsetAsync(d, 0x80, 4 * sizeof(int), h->stream));
+    hipLaunchKernelGGL(buoy_box_kernel, dim3(std::min(nblocks(h->nP, 4 * kBlock), 2048u)), dim3(kBlock), 0, h->stream, h->nP, h->st[h->cur].cell, d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h->box_host, d, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipEventRecord(h->box_ev, h->stream));
+    return SITRK_OK;
+}
+
+SITRK_API int sitrk_buoy_box_end(sitrk_t *h, int32_t *jmin, int32_t *jmax, int32_t *imin, int32_t *imax, int32_t *age)
+{
+    NEED(h, "null handle");
+    NEED(h->box_pending, "sitrk_buoy_box_end: nothing begun");
+    NEED(jmin && jmax && imin && imax, "sitrk_buoy_box_end: null output");
+    if (h->nP > 0) HIPCHK(hipEventSynchronize(h->box_ev));
+    h->box_pending = false;
+    if (h->nP > 0 && h->box_host[0] >= 0) {
+        h->band_jmax = h->box_host[0]; h->band_jmin = -h->box_host[1]; h->band_imax = h->box_host[2]; h->band_imin = -h->box_host[3];
+    } else {
+        h->band_jmin = 1; h->band_jmax = 0; h->band_imin = 1; h->band_imax = 0;
+    }
+    h->band_age = h->box_pending_age;
+    *jmin = h->band_jmin; *jmax = h->band_jmax; *imin = h->band_imin; *imax = h->band_imax;
+    if (age) *age = h->band_age;
+    return SITRK_OK;
+}
+
 SITRK_API int sitrk_push_record_rows(sitrk_t *h, int slot, int j0, int j1, const void *u_rows, const void *v_rows, const void *sic_rows)
 {
     NEED(h, "null handle");
@@ -618,11 +697,11 @@ SITRK_API int sitrk_push_record_rows(sitrk_t *h, int slot, int j0, int j1, const
     NEED(j0 >= 0 && j1 <= h->Nj && j0 <= j1, "sitrk_push_record_rows: rows out of range");
     if (j0 == j1) { slot_holds(h, slot, 0, 0, 0, 0); return SITRK_OK; }
     NEED(u_rows && v_rows && sic_rows, "sitrk_push_record_rows: null field");
-    return push_box(h, slot, j0, j1, 0, h->Ni, u_rows, v_rows, sic_rows);
+    return push_box(h, slot, j0, j1, 0, h->Ni, u_rows, v_rows, sic_rows, h->Ni);
 }
 
 SITRK_API int sitrk_push_record_box(sitrk_t *h, int slot, int j0, int j1, int i0, int i1, const void *u_box, const void *v_box,
-                                    const void *sic_box)
+                                    const void *sic_box, int64_t ld)
 {
     NEED(h, "null handle");
     NEED(h->slabs, "sitrk_push_record_box: call sitrk_alloc_records first");
@@ -630,7 +709,8 @@ SITRK_API int sitrk_push_record_box(sitrk_t *h, int slot, int j0, int j1, int i0
     NEED(j0 >= 0 && j1 <= h->Nj && j0 <= j1 && i0 >= 0 && i1 <= h->Ni && i0 <= i1, "sitrk_push_record_box: box out of range");
     if (j0 == j1 || i0 == i1) { slot_holds(h, slot, 0, 0, 0, 0); return SITRK_OK; }
     NEED(u_box && v_box && sic_box, "sitrk_push_record_box: null field");
-    return push_box(h, slot, j0, j1, i0, i1, u_box, v_box, sic_box);
+    NEED(ld >= (int64_t)(i1 - i0), "sitrk_push_record_box: ld is smaller than the box is wide");
+    return push_box(h, slot, j0, j1, i0, i1, u_box, v_box, sic_box, ld);
 }
 
 SITRK_API int sitrk_commit_record_rows(sitrk_t *h, int slot, int j0, int j1)
@@ -733,7 +813,7 @@ SITRK_API int sitrk_set_buoys(sitrk_t *h, int64_t nP, const double *yx, const in
     free_buoys(h);
     h->windowed = (rec_first != nullptr);
     h->cur = 0; h->steps_since_sort = 0; h->sorted_once = false;
-    h->band_age = -1;
+    h->band_age = -1; h->box_pending = false;
     // host-side validation + packing of the host cell
     std::vector<int32_t> packed;
     try {
@@ -925,7 +1005,7 @@ SITRK_API int sitrk_step(sitrk_t *h, int slot, int jrec)
     StepArgs a;
     a.nP = h->nP; a.tune = h->tune; a.Nj = h->Nj; a.Ni = h->Ni; a.jrec = jrec;
     a.rdt = h->rdt; a.rmin_conc = h->rmin_conc; a.eps_mg = h->eps_mg;
-    a.geo = h->geo; a.orient = h->orient; a.kill = h->kill + (size_t)slot * n;
+    a.geo = h->geo; a.orient = h->orient; a.kill = h->kill9 + (size_t)slot * n;
     a.u = slab; a.v = slab + n * es;
     a.pos = s.pos; a.cell = s.cell; a.kill_rec = s.kill_rec; a.win = s.win;
     if (h->dtype == SITRK_F64) launch_step<double>(h, a);
@@ -936,6 +1016,7 @@ SITRK_API int sitrk_step(sitrk_t *h, int slot, int jrec)
     h->steps_since_sort++;
     h->n_step_launches++;
     if (h->band_age >= 0) h->band_age++;
+    if (h->box_pending) h->box_pending_age++;
     return SITRK_OK;
 }
 
@@ -1048,6 +1129,7 @@ SITRK_API int sitrk_run(sitrk_t *h, int slot0, int jrec0, int nsteps)
         h->n_fused_launches++;
         h->n_fused_records += m;
         if (h->band_age >= 0) h->band_age += m;
+        if (h->box_pending) h->box_pending_age += m;
         k += m;
     }
     return SITRK_OK;
@@ -1439,21 +1521,18 @@ SITRK_API int sitrk_eval_crossing(sitrk_t *h, int64_t n, const double *P1, const
             return fail(h, SITRK_EINDEX, "sitrk_eval_crossing: host cell (%d,%d) outside 1..%d x 1..%d", jiT[2 * p], jiT[2 * p + 1],
                         h->Nj - 2, h->Ni - 2);
     HIPCHK(hipSetDevice(h->device));
-    const size_t cells = (size_t)h->Nj * h->Ni;
-    const size_t b_p = align256((size_t)n * sizeof(pt)), b_j = align256((size_t)n * 8), b_m = align256(cells);
-    int rc = ensure_scratch(h, 2 * b_p + 3 * b_j + b_m);
+    const size_t b_p = align256((size_t)n * sizeof(pt)), b_j = align256((size_t)n * 8);
+    int rc = ensure_scratch(h, 2 * b_p + 3 * b_j);
     if (rc) return rc;
     char *s = (char *)h->scratch;
     pt *d1 = (pt *)s, *d2 = (pt *)(s + b_p);
     int32_t *dj = (int32_t *)(s + 2 * b_p), *dn = (int32_t *)(s + 2 * b_p + b_j), *dc = (int32_t *)(s + 2 * b_p + 2 * b_j);
-    int8_t *zero = (int8_t *)(s + 2 * b_p + 3 * b_j);
     HIPCHK(hipMemcpyAsync(d1, P1, (size_t)n * sizeof(pt), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(d2, P2, (size_t)n * sizeof(pt), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(dj, jiT, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemsetAsync(zero, 0, cells, h->stream));
     CrossTab tab;
     make_cross_tab(h->Ni, tab);
-    hipLaunchKernelGGL(eval_crossing_kernel, dim3(nblocks(n)), dim3(kBlock), 0, h->stream, n, h->Nj, h->Ni, h->geo, zero, d1, d2, dj, dn,
+    hipLaunchKernelGGL(eval_crossing_kernel, dim3(nblocks(n)), dim3(kBlock), 0, h->stream, n, h->Nj, h->Ni, h->geo, d1, d2, dj, dn,
                        codes ? dc : nullptr, tab);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(jiT_new, dn, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));

@@ -65,13 +65,13 @@ struct sitrk_ctx {
     int patch_kb = 16;                  // fused kernel: LDS bytes per workgroup for its geometry patch (0 = none, all reads global)
     int xcd_group = 16;                 // fused kernel: runs of that many consecutive workgroups on one XCD (0/1 = hardware order)
     int patch_margin = 8;               // ... and the widest margin of cells around the buoys' bounding box it may take
+    int fill_threads = 8;               // host threads copying a pushed record (>= 8 MB) into the pinned staging (2 / 4 / 8: 26 / 36 / 47 GB/s on the box rows of C3)
 
     // records
     int nslots = 0, dtype = 0;
     size_t slab_bytes = 0;
     void *slabs = nullptr;              // nslots * [u|v|sic]
-    int8_t *kill = nullptr;             // nslots * (Nj*Ni) Survive masks derived from (tmask, sic, rmin_conc)
-    uint8_t *kill9 = nullptr;           // nslots * (Nj*Ni) 3x3 neighbourhoods of those bytes, one word per cell (fused kernel)
+    uint8_t *kill9 = nullptr;           // nslots * (Nj*Ni): per cell the Survive bytes (tmask, sic, rmin_conc) of its 8 neighbours, one bit each
     unsigned char slot_dirty[4096] = {0};   // slab (re)written since its mask was derived
     // per slot: upload still in flight on copy_stream (the compute stream waits for slot_ready before it reads the
     // slot; events are created on first use), and the sequence number of the last launch that reads the slot (an upload
@@ -91,6 +91,12 @@ struct sitrk_ctx {
     // since (a host cell moves at most one row and one column per record): what a partly uploaded slot is checked against
     int band_jmin = 0, band_jmax = -1, band_age = -1;      // band_age < 0: not evaluated since sitrk_set_buoys
     int band_imin = 0, band_imax = -1;
+    // asynchronous evaluation (sitrk_buoy_box_begin / _end): the reduction is queued on the compute stream, its result lands in
+    // pinned host memory behind an event; records stepped after the begin are counted separately until the end adopts the result
+    int *box_host = nullptr;            // 4 ints, pinned
+    hipEvent_t box_ev = nullptr;
+    bool box_pending = false;
+    int box_pending_age = 0;
     // launch accounting (sitrk_launch_stats)
     long long n_fused_launches = 0, n_fused_records = 0, n_step_launches = 0;
 

@@ -81,12 +81,14 @@ __device__ __forceinline__ bool survive_kill(int jT, int iT, int Nj, int Ni, con
 // Per-record Survive bytes, ONE pass over a record (or over an uploaded row band).  `Survive` (tracking.py:62-93)
 // depends only on the cell and on the record's ice concentration, so it is evaluated ONCE PER CELL when a record
 // becomes resident (same tests, same order, same left-to-right fp64 sum) and the crossing path reads one byte instead
-// of chasing two dependent 5-point stencils through memory.  Two outputs per cell:
-//   kill [j,i]  the Survive byte itself (the one-record kernel's crossing path reads three of them);
+// of chasing two dependent 5-point stencils through memory.  Outputs per cell:
 //   kill9[j,i]  the Survive bytes of the cell's 8 neighbours, bit b = cell (j+dj, i+di) with (dj+1)*3 + (di+1) = b for
-//               b < 4 and b + 1 otherwise (the centre is never a destination): the fused kernel requests this ONE byte
+//               b < 4 and b + 1 otherwise (the centre is never a destination): both stepping kernels request this ONE byte
 //               per buoy and record together with the velocities, at the top of a record's iteration, not behind the
 //               crossing test -- it is the one crossing-path operand that is new with every record, i.e. never in cache.
+//               (Round 4: the one-record kernel gathered three bytes of `kill` before; a record now has one Survive product:
+//               6 bytes of traffic per cell instead of 7 and one array per slot instead of two.)
+//   kill [j,i]  the Survive byte itself, only when asked for (the probe sitrk_survive_mask: `kill` may be null);
 // A workgroup owns a tile of 32 x 64 cells: the tile's siconc and tmask with a halo of two cells go to LDS by row-wise
 // coalesced loads, the Survive bytes of the tile and a halo of one cell are evaluated from LDS into LDS, and every
 // thread then packs strips of four cells (one 32-bit store per output).  Rows: [j_lo, j_hi) are written, of which the
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(kSvBlock) void survive_kill9_kernel(int Nj, int Ni,
                                                                 double rmin_conc, int8_t *__restrict__ kill0, uint8_t *__restrict__ kill90)
 {
     const FT *__restrict__ sic = sic0 + (size_t)sb.slot[blockIdx.z] * (size_t)sb.sic_stride;
-    int8_t *__restrict__ kill = kill0 + (size_t)sb.slot[blockIdx.z] * (size_t)sb.kill_stride;
+    int8_t *__restrict__ kill = kill0 ? kill0 + (size_t)sb.slot[blockIdx.z] * (size_t)sb.kill_stride : nullptr;    // (probes only)
     uint8_t *__restrict__ kill9 = kill90 + (size_t)sb.slot[blockIdx.z] * (size_t)sb.kill_stride;
     __shared__ FT s_sic[kSvSR * kSvSC];
     __shared__ int8_t s_tm[kSvSR * kSvSC];
@@ -206,14 +208,16 @@ __global__ __launch_bounds__(kSvBlock) void survive_kill9_kernel(int Nj, int Ni,
         const unsigned wk = (unsigned)(R1 >> 8);                                      // the strip's own four Survive bytes
         const size_t k = (size_t)j * Ni + i0;
         if (vec && i0 + 4 <= bx.c_hi) {
-            if (wrm == 0xfu) *(unsigned *)(kill + k) = wk;
-            else
-                for (int q = 0; q < 4; q++)
-                    if ((wrm >> q) & 1u) kill[k + q] = (int8_t)((wk >> (8 * q)) & 0xffu);
+            if (kill) {
+                if (wrm == 0xfu) *(unsigned *)(kill + k) = wk;
+                else
+                    for (int q = 0; q < 4; q++)
+                        if ((wrm >> q) & 1u) kill[k + q] = (int8_t)((wk >> (8 * q)) & 0xffu);
+            }
             *(unsigned *)(kill9 + k) = w9;
         } else {
             for (int q = 0; q < 4 && i0 + q < Ni && i0 + q < bx.c_hi; q++) {
-                if ((wrm >> q) & 1u) kill[k + q] = (int8_t)((wk >> (8 * q)) & 0xffu);
+                if (kill && ((wrm >> q) & 1u)) kill[k + q] = (int8_t)((wk >> (8 * q)) & 0xffu);
                 kill9[k + q] = (uint8_t)((w9 >> (8 * q)) & 0xffu);
             }
         }
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(256) void survive_kill9_rows_kernel(int Nj, int Ni,
                                                                 double rmin_conc, int8_t *__restrict__ kill0, uint8_t *__restrict__ kill90)
 {
     const FT *__restrict__ sic = sic0 + (size_t)sb.slot[blockIdx.z] * (size_t)sb.sic_stride;
-    int8_t *__restrict__ kill = kill0 + (size_t)sb.slot[blockIdx.z] * (size_t)sb.kill_stride;
+    int8_t *__restrict__ kill = kill0 ? kill0 + (size_t)sb.slot[blockIdx.z] * (size_t)sb.kill_stride : nullptr;    // (probes only)
     uint8_t *__restrict__ kill9 = kill90 + (size_t)sb.slot[blockIdx.z] * (size_t)sb.kill_stride;
     static_assert(sizeof(FT) == 4 || sizeof(FT) == 8, "records are binary32 or binary64");
 #if !defined(__gfx9__) && !defined(__GFX9__) && defined(__HIP_DEVICE_COMPILE__)
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(256) void survive_kill9_rows_kernel(int Nj, int Ni,
                     wk |= ((K1 >> (q + 1)) & 1u) << (8 * q);
                 }
                 const size_t k = (size_t)jo * Ni + g0;
-                if (wr_kill) {
+                if (wr_kill && kill) {
                     if (dvc == 0xfu) *(unsigned *)(kill + k) = wk;
                     else                                                              // (a box's edge groups only)
                         for (int q = 0; q < 4; q++)
@@ -402,30 +406,36 @@ __global__ __launch_bounds__(256) void survive_kill9_rows_kernel(int Nj, int Ni,
     }
 }
 
-// rows and columns of the host cells of the buoys that are still alive: out = {min jT, max jT, min iT, max iT}
+// rows and columns of the host cells of the buoys that are still alive, as FOUR MAXIMA: out = {max jT, max -jT, max iT, max -iT}
+// (one identity for all four: the host fills `out` with a very negative pattern by one memset).  16-byte loads; a workgroup
+// touches the result only where it improves on what is there (same-address atomics serialise at the memory side: 2048 workgroups
+// x 4 atomics cost 100 us at 1e7 buoys, the reads 15 us; a stale read can only make a workgroup try an atomic it did not need).
 __global__ __launch_bounds__(kBlock) void buoy_box_kernel(int64_t n, const int32_t *__restrict__ cell, int *out)
 {
     __shared__ int sm[4][kBlock / 64];
-    int lo = 0x7fffffff, hi = -1, ilo = 0x7fffffff, ihi = -1;
-    for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < n; s += (int64_t)gridDim.x * kBlock) {
-        const int32_t c = cell[s];
+    int m0 = INT32_MIN, m1 = INT32_MIN, m2 = INT32_MIN, m3 = INT32_MIN;
+    auto take = [&](int32_t c) {
         if (c >= 0) {
             const int j = cell_j(c), i = cell_i(c);
-            lo = min(lo, j); hi = max(hi, j); ilo = min(ilo, i); ihi = max(ihi, i);
+            m0 = max(m0, j); m1 = max(m1, -j); m2 = max(m2, i); m3 = max(m3, -i);
         }
+    };
+    const int64_t n4 = n >> 2;
+    for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < n4; s += (int64_t)gridDim.x * kBlock) {
+        const int4 c = ((const int4 *)cell)[s];                     // (hipMalloc'ed: 256-byte aligned)
+        take(c.x); take(c.y); take(c.z); take(c.w);
     }
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n & 3)) take(cell[4 * n4 + threadIdx.x]);
     for (int off = 32; off > 0; off >>= 1) {
-        lo = min(lo, __shfl_down(lo, off)); hi = max(hi, __shfl_down(hi, off));
-        ilo = min(ilo, __shfl_down(ilo, off)); ihi = max(ihi, __shfl_down(ihi, off));
+        m0 = max(m0, __shfl_down(m0, off)); m1 = max(m1, __shfl_down(m1, off));
+        m2 = max(m2, __shfl_down(m2, off)); m3 = max(m3, __shfl_down(m3, off));
     }
-    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; sm[0][w] = lo; sm[1][w] = hi; sm[2][w] = ilo; sm[3][w] = ihi; }
+    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; sm[0][w] = m0; sm[1][w] = m1; sm[2][w] = m2; sm[3][w] = m3; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < kBlock / 64; w++) { lo = min(lo, sm[0][w]); hi = max(hi, sm[1][w]); ilo = min(ilo, sm[2][w]); ihi = max(ihi, sm[3][w]); }
-        atomicMin(&out[0], lo);
-        atomicMax(&out[1], hi);
-        atomicMin(&out[2], ilo);
-        atomicMax(&out[3], ihi);
+    if (threadIdx.x < 4) {
+        int m = sm[threadIdx.x][0];
+        for (int w = 1; w < kBlock / 64; w++) m = max(m, sm[threadIdx.x][w]);
+        if (m > __atomic_load_n(&out[threadIdx.x], __ATOMIC_RELAXED)) atomicMax(&out[threadIdx.x], m);
     }
 }
 
@@ -436,12 +446,12 @@ __device__ __forceinline__ pt load_f(const CellGeo *__restrict__ geo, int j, int
 
 // CrossedEdge + NewHostCell + UpdtInd4NewCell + Survive   reference sitrack/tracking.py:62-93,182-305
 // quad = [bl, br, ur, ul] of the current cell (jT,iT).  Returns the new packed cell (dead bit set when
-// Survive kills).  CrossedEdge needs only the quad (registers); everything that must come from memory
-// afterwards -- the two grid-line extension points of NewHostCell and the Survive bytes of the three
-// cells the buoy can have entered -- is then loaded in ONE batch of independent loads, so the crossing
-// path costs one memory round trip instead of a chain of four.
+// Survive kills).  CrossedEdge needs only the quad (registers); what must come from memory afterwards --
+// the two grid-line extension points of NewHostCell -- is loaded in one batch of independent loads; the
+// Survive bytes of the three cells the buoy can have entered are bits of k9, the host cell's packed
+// neighbourhood byte of this record (loaded with the velocities: round 4, three byte gathers before).
 __device__ __forceinline__ int32_t resolve_crossing(pt P1, pt P2, pt bl, pt br, pt ur, pt ul, int jT, int iT, int Nj, int Ni,
-                                                    const CellGeo *__restrict__ geo, const int8_t *__restrict__ kill,
+                                                    const CellGeo *__restrict__ geo, unsigned k9,
                                                     bool &killed, int *codes = nullptr)
 {
     // CrossedEdge (:189-200): first of bottom, right, upper, left hit; falls through to 4.
@@ -476,10 +486,10 @@ __device__ __forceinline__ int32_t resolve_crossing(pt P1, pt P2, pt bl, pt br, 
     // one batch of independent loads (only the extension points can index below zero, and then numpy wraps)
     const pt eA = load_f(geo, jA, iA, Nj, Ni);
     const pt eB = load_f(geo, jB, iB, Nj, Ni);
-    const int kT = jT * Ni + iT;                                            // < 2^31 (sitrk_set_grid)
-    const int8_t kS = kill[(unsigned)(kT + djS * Ni + diS)];
-    const int8_t kA = kill[(unsigned)(kT + djA * Ni + diA)];
-    const int8_t kB = kill[(unsigned)(kT + djB * Ni + diB)];
+    // the Survive bytes of the three cells the buoy can have entered: bits of the host cell's packed neighbourhood (kill9),
+    // bit b = cell (jT+dj, iT+di) with (dj+1)*3 + (di+1) = b for b < 4 and b + 1 otherwise
+    auto nb_bit = [](int dj, int di) { const int b9 = (dj + 1) * 3 + (di + 1); return 1u << (b9 < 4 ? b9 : b9 - 1); };
+    const bool kS = (k9 & nb_bit(djS, diS)) != 0, kA = (k9 & nb_bit(djA, diA)) != 0, kB = (k9 & nb_bit(djB, diB)) != 0;
     const bool sva = (kc == 1) ? sbl : (kc == 2) ? sbr : sul;               // ccw(P1,P2,va), already known
     const bool svb = (kc == 1) ? sbr : (kc == 4) ? sbl : sur;
     const bool hitA = (ccw(P1, va, eA) != ccw(P2, va, eA)) && (sva != ccw(P1, P2, eA));
@@ -487,7 +497,7 @@ __device__ __forceinline__ int32_t resolve_crossing(pt P1, pt P2, pt bl, pt br, 
     // UpdtInd4NewCell (:257-300); first match wins (if / elif)
     const int dj = hitA ? djA : (hitB ? djB : djS);
     const int di = hitA ? diA : (hitB ? diB : diS);
-    killed = (hitA ? kA : (hitB ? kB : kS)) != 0;                           // Survive (:483-484)
+    killed = hitA ? kA : (hitB ? kB : kS);                                  // Survive (:483-484)
     if (codes) {                                                            // probes only: CrossedEdge / NewHostCell return values
         const int cA = (kc == 1) ? 5 : (kc == 2) ? 6 : 8, cB = (kc == 1) ? 6 : (kc == 4) ? 5 : 7;
         codes[0] = kc;
@@ -651,7 +661,7 @@ struct StepArgs {
     double eps_mg;                      // 2^-48 * max |F-point coordinate| : margin scale of inside_quad_hot
     const CellGeo *geo;
     const int8_t *orient;               // per-cell orientation bits (cell_orient_kernel)
-    const int8_t *kill;                 // the record's Survive mask (survive_mask_kernel)
+    const uint8_t *kill;                // the record's packed Survive neighbourhoods, one byte per cell (kill9 of survive_kill9_*_kernel)
     const void *u, *v;
     pt *pos;
     int32_t *cell;
@@ -668,7 +678,7 @@ struct StepArgs {
 // ---------------------------------------------------------------------------
 template <typename FT, int UVS>
 __device__ __forceinline__ bool advance_record(const StepArgs &a, const FT *__restrict__ u, const FT *__restrict__ v,
-                                               const int8_t *__restrict__ kill, pt &P, int32_t &c)
+                                               const uint8_t *__restrict__ kill9, pt &P, int32_t &c)
 {
     const int Ni = a.Ni, Nj = a.Nj;
     const int jT = cell_j(c), iT = cell_i(c);
@@ -709,7 +719,7 @@ __device__ __forceinline__ bool advance_record(const StepArgs &a, const FT *__re
     bool killed = false;
     // still inside the host cell? (:466) quad = [bl, br, ur, ul]
     if (!inside_quad(Pn.y, Pn.x, F00, F01, g11.f, F10))
-        c = resolve_crossing(P, Pn, F00, F01, g11.f, F10, jT, iT, Nj, Ni, a.geo, kill, killed);   // :474-484
+        c = resolve_crossing(P, Pn, F00, F01, g11.f, F10, jT, iT, Nj, Ni, a.geo, (unsigned)kill9[k], killed);   // :474-484
     P = Pn;
     return !killed;
 }
@@ -1235,7 +1245,7 @@ __global__ void eval_intersect_kernel(int64_t n, const pt *__restrict__ segs, in
     if (ccw_abc) ccw_abc[k] = ccw(A, B, Cc) ? 1 : 0;
 }
 
-__global__ void eval_crossing_kernel(int64_t n, int Nj, int Ni, const CellGeo *__restrict__ geo, const int8_t *__restrict__ zero_mask,
+__global__ void eval_crossing_kernel(int64_t n, int Nj, int Ni, const CellGeo *__restrict__ geo,
                                      const pt *__restrict__ P1, const pt *__restrict__ P2, const int32_t *__restrict__ jiT,
                                      int32_t *__restrict__ jiT_new, int32_t *__restrict__ codes_out, CrossTab tab)
 {
@@ -1249,7 +1259,7 @@ __global__ void eval_crossing_kernel(int64_t n, int Nj, int Ni, const CellGeo *_
     bool killed;
     int codes[2];
     const pt bl = geo[k - Ni - 1].f, br = geo[k - Ni].f, ur = geo[k].f, ul = geo[k - 1].f;
-    int32_t cn = resolve_crossing(P1[p], P2[p], bl, br, ur, ul, jT, iT, Nj, Ni, geo, zero_mask, killed, codes);
+    int32_t cn = resolve_crossing(P1[p], P2[p], bl, br, ur, ul, jT, iT, Nj, Ni, geo, 0u, killed, codes);
     // the table-driven form of the fused kernel (cells it is used for: no negative-index wrap; 32-bit byte offsets)
     if (jT >= 2 && iT >= 2 && (size_t)Nj * Ni * sizeof(CellGeo) < ((size_t)1 << 32)) {
         int dcell, dk, codes2[2];

@@ -99,6 +99,35 @@ def nearest_t_plane(grid, yx):
     return np.stack([np.clip(j, 2, Nj - 3), np.clip(i, 2, Ni - 3)], axis=1).astype(np.int64)
 
 
+def nearest_t_index(grid, yx, iters=6):
+    """Nearest T-point of (y,x) positions on a make_grid() mesh with warp > 0 by inverting _index_to_plane with a few
+    fixed-point sweeps (the warp terms move a point by a fraction of a cell and vary over the whole mesh, so the map
+    contracts fast): O(nP), no tree -- what bench-size buoy sets (1e7) on warped meshes are seeded with, as the guess
+    for the library's own FindContainingCell."""
+    Nj, Ni, dkm, warp = grid["Nj"], grid["Ni"], grid["dkm"], grid["warp"]
+    y0, x0 = float(grid.get("y_shift", 0.0)), float(grid.get("x_shift", 0.0))
+    y, x = yx[:, 0] - y0, yx[:, 1] - x0
+    jj = y / dkm + 0.5 * (Nj - 1)
+    ii = x / dkm + 0.5 * (Ni - 1)
+    for _ in range(iters if warp else 0):
+        jj = (y - warp * 0.30 * dkm * np.sin(2.0 * np.pi * 1.3 * ii / Ni + 0.3)) / dkm + 0.5 * (Nj - 1)
+        ii = (x - warp * 0.20 * dkm * np.sin(2.0 * np.pi * jj / Nj)) / (dkm * (1.0 + warp * 0.05 * (jj / Nj))) + 0.5 * (Ni - 1)
+    j = np.rint(jj).astype(np.int64)
+    i = np.rint(ii).astype(np.int64)
+    return np.stack([np.clip(j, 2, Nj - 3), np.clip(i, 2, Ni - 3)], axis=1)
+
+
+def shift_grid(grid, dy, dx):
+    """move the whole mesh in the plane (a NANUK4-like mesh does not sit on the pole)"""
+    for k in ("Yt", "Yu", "Yv", "Yf"):
+        grid[k] = grid[k] + dy
+    for k in ("Xt", "Xu", "Xv", "Xf"):
+        grid[k] = grid[k] + dx
+    grid["y_shift"] = grid.get("y_shift", 0.0) + dy
+    grid["x_shift"] = grid.get("x_shift", 0.0) + dx
+    return grid
+
+
 def make_buoys(grid, nP, seed=1234, frac=0.6):
     """Uniform random buoys in the central `frac` of the domain; IDs 1..nP (int64)."""
     rng = np.random.default_rng(seed)

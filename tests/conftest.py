@@ -72,6 +72,34 @@ def g6b_case(g):
     return grid, u, v, sic
 
 
+_CUT_CACHE = {}
+
+
+def baseline_cut_case(g):
+    """Golden sets G6c / G6d (the reference's trajectories on the first 10^3 buoys x 100 records of the real C2 / C3 workloads
+    of bench.py): grid, the 32 resident records and the buoys' positions rebuilt from the stored seeds exactly as bench.py builds
+    them, guarded by checksums.  Cached per mesh size (the 4096^2 fields are 6.4 GB)."""
+    from sitrack_amd import synthetic as syn
+    Nj, Ni, dkm, warp = g["mesh"]
+    nAll, bseed, nP = (int(x) for x in g["buoys"])
+    K, fseed, umax, drift = g["fields"]
+    key = (int(Nj), int(Ni))
+    if key not in _CUT_CACHE:
+        _CUT_CACHE.clear()
+        grid = syn.make_grid(int(Nj), int(Ni), dkm=float(dkm), warp=float(warp))
+        _, yx = syn.make_buoys(grid, nAll, seed=bseed, frac=0.6)
+        yx0 = np.ascontiguousarray(yx[:nP])
+        del yx
+        u, v, sic = syn.make_fields(grid, K=int(K), seed=int(fseed), umax=float(umax), drift=float(drift))
+        ok = yx0.sum() == float(g["yx0_sum"]) and (sic == 1).all() and float(g["sic_sum"]) == float(sic.size)
+        for q, k in enumerate(g["probe_records"]):
+            ok = ok and u[k].astype(np.float64).sum() == g["u_sum"][q] and v[k].astype(np.float64).sum() == g["v_sum"][q]
+        assert ok, "the rebuilt workload differs from the one the golden outputs were generated on"
+        assert np.array_equal(syn.regular_host_cell(grid, yx0), g["jiT0"])
+        _CUT_CACHE[key] = (grid, u, v, sic, yx0)
+    return _CUT_CACHE[key]
+
+
 def traj_digest_row(pos, msk, jit, alive):
     """one record's digest as tests/golden/gen_golden.py::traj_digest forms it"""
     m = msk == 1

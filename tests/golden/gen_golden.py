@@ -555,6 +555,64 @@ def g6b_fast_flow_trajectories():
          kstrt=np.int64(kstrt), Nt=np.int64(Nt), rdt=np.float64(rdt), **out)
 
 
+PROBE_RECORDS = [0, 5, 10, 15, 20, 25, 30, 31]       # records whose exact fp64 sums guard the rebuilt BASELINE fields (G6c / G6d)
+
+
+def g6cd_baseline_cuts(configs=("c2", "c3"), nP=1000, Nt=100):
+    """G6c / G6d: REFERENCE trajectories on the BASELINE workloads themselves.  The first 10^3 buoys x 100
+    records of the real C2 (512^2, 1e5 buoys) and C3 (4096^2, 1e7 buoys) inputs of bench.py -- same grid, same buoy seed
+    default_rng(1234), same 32 resident records of default_rng(2024) cycled -- through the restated reference loop, both
+    velocity rules, once with every buoy stepping every record and once with 12 late starters / 12 early stoppers like G6
+    (per-buoy record windows, si3_part_tracker.py:264-318,380).  Stored: host cells at the start, windows, final state and
+    per-record digests (traj_digest); positions, grid and fields are rebuilt by the tests from the seeds and guarded by
+    checksums.  Until round 3 the BASELINE grids were held against the oracle only (tools/time_reference_loop.py threw these
+    trajectories away)."""
+    from sitrack_amd.tracking import vertices_of
+    shapes = {"c2": (512, 512, 100_000, "g6c_c2cut.npz"), "c3": (4096, 4096, 10_000_000, "g6d_c3cut.npz")}
+    K, kstrt, rdt = 32, 0, 3600.
+    for cfg in configs:
+        Nj, Ni, nAll, fname = shapes[cfg]
+        g = syn.make_grid(Nj, Ni, dkm=4.0, warp=0.0)
+        _, yx = syn.make_buoys(g, nAll, seed=1234, frac=0.6)
+        yx0 = np.ascontiguousarray(yx[:nP])
+        del yx
+        jiT0 = syn.regular_host_cell(g, yx0).astype(np.int64)
+        # the reference's own FindContainingCell agrees with the analytic host cell on every buoy of the cut
+        for b in range(0, nP, 7):
+            ok, ji, _ = locate.FindContainingCell((yx0[b, 0], yx0[b, 1]), (int(jiT0[b, 0]), int(jiT0[b, 1])), g["Yf"], g["Xf"])
+            assert ok and tuple(ji) == tuple(jiT0[b]), (cfg, b)
+        vert0 = vertices_of(jiT0)
+        u, v, sic = syn.make_fields(g, K=K, seed=2024, umax=0.3, drift=0.05)
+        rng = np.random.default_rng(1239)
+        wf = np.full(nP, kstrt, dtype=np.int64); wl = np.full(nP, kstrt + Nt - 1, dtype=np.int64)
+        late = rng.choice(nP, 12, replace=False); wf[late] = kstrt + rng.integers(1, 20, 12)
+        early = rng.choice(nP, 12, replace=False); wl[early] = kstrt + Nt - 1 - rng.integers(1, 20, 12)
+        all_f = np.full(nP, kstrt, dtype=np.int64); all_l = np.full(nP, 10**9, dtype=np.int64)
+        out = {}
+        for strat in (1, 0):
+            for tag, (rf, rl) in (("", (all_f, all_l)), ("w", (wf, wl))):
+                with quiet():
+                    pos, msk, jit_rec, alive_rec, vert, codes = reference_loop(g, g["tmask"], u, v, sic, yx0, jiT0, vert0, rf, rl, kstrt, Nt, rdt, strat)
+                last = np.full((nP, 2), FILL)
+                for k in range(Nt + 1):
+                    m = msk[k] == 1
+                    last[m] = pos[k][m]
+                key = "s%d%s" % (strat, tag)
+                out["digest_" + key] = traj_digest(pos, msk, jit_rec, alive_rec)
+                out["last_pos_" + key] = last
+                out["jiT_end_" + key] = jit_rec[-1].astype(np.int32)
+                out["alive_end_" + key] = alive_rec[-1]
+                out["codes_" + key] = codes
+                print("   %s strat %d %-8s: %d particle-steps, crossings by code %s, dead %d/%d" %
+                      (fname, strat, "windows" if tag else "all", int(msk[1:].sum()), codes[1:].tolist(), int((alive_rec[-1] == 0).sum()), nP))
+        save(fname, mesh=np.array([Nj, Ni, 4.0, 0.0]), buoys=np.array([nAll, 1234, nP]), fields=np.array([K, 2024, 0.3, 0.05]),
+             probe_records=np.array(PROBE_RECORDS), u_sum=np.array([u[k].astype(np.float64).sum() for k in PROBE_RECORDS]),
+             v_sum=np.array([v[k].astype(np.float64).sum() for k in PROBE_RECORDS]), sic_sum=np.float64(sic.sum(dtype=np.float64)),
+             yx0_sum=np.float64(yx0.sum()),
+             jiT0=jiT0.astype(np.int32), rec_first=wf, rec_last=wl, kstrt=np.int64(kstrt), Nt=np.int64(Nt), rdt=np.float64(rdt), **out)
+        del g, u, v, sic
+
+
 # --------------------------------------------------------------------------- G7
 def h5_values(path, name, fmt):
     txt = subprocess.run(["/opt/conda/bin/h5dump", "-m", fmt, "-d", name, path], check=True,
@@ -624,7 +682,8 @@ def g10_nemoseed():
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, fn in (("g1", g1_inside), ("g2", g2_intersect), ("g3", g3_crossing), ("g4", g4_survive), ("g4b", g4b_survive_wide),
-                     ("g5", g5_seedinit), ("g5b", g5b_seedinit_on_points), ("g5c", g5c_seedinit_larger_mesh), ("g6", g6_trajectories), ("g6b", g6b_fast_flow_trajectories), ("g7", g7_projection), ("g8", g8_timespan),
+                     ("g5", g5_seedinit), ("g5b", g5b_seedinit_on_points), ("g5c", g5c_seedinit_larger_mesh), ("g6", g6_trajectories), ("g6b", g6b_fast_flow_trajectories), ("g6cd", g6cd_baseline_cuts),
+                     ("g7", g7_projection), ("g8", g8_timespan),
                      ("g9", g9_haversine), ("g10", g10_nemoseed)):
         if not only or name in only:
             fn()

@@ -198,3 +198,14 @@ def test_nemoseed_matches_reference_golden(golden):
             assert (nT, nF) == (len(wantT), len(wantF)) and np.array_equal(ll, np.concatenate([wantT, wantF]), equal_nan=True)
     finally:
         ctx.close()
+
+
+def test_roofline_goes_stale_when_the_kernel_changes():
+    """the roofline's constants come from counter passes of ONE binary: another fingerprint (an edited kernel) flips `stale`"""
+    import bench
+    shipped = bench.isa_fingerprint()
+    assert shipped and len(shipped["sha256"]) == 16                   # written by the build next to the library
+    assert bench.roofline_is_stale(dict(shipped), shipped) is False
+    edited = dict(shipped, sha256="0" * 16)
+    assert bench.roofline_is_stale(edited, shipped) is True and bench.roofline_is_stale(None, shipped) is True
+    assert bench.roofline_is_stale(shipped, None) is True

@@ -42,24 +42,43 @@ def test_c2_full_1000_steps_checked_by_the_oracle():
 
 
 def test_c3_full_1000_steps_checked_by_the_oracle():
-    """the headline workload at the length BASELINE quotes it: 1e7 buoys x 1000 records (+ the two reference legs of the
-    same run), first 20 000 buoys bit-exact against the oracle at the end"""
+    """the headline workload at the length BASELINE quotes it: 1e7 buoys x 1000 records (+ the fresh-records leg and the two
+    reference legs of the same run), first 20 000 buoys bit-exact against the oracle at the end"""
     d, err = _bench(["--steps", "1000", "--warmup", "50", "--check", "--no-cpu-baseline", "--no-c2"])
-    assert "check OK" in err, err[-2000:]
+    assert "check OK" in err and "after 4050 steps" in err, err[-2000:]          # warm-up + headline + fresh + per-record + 8-per-launch legs
     assert d["config"]["grid"] == [4096, 4096] and d["config"]["buoys_per_gpu"] == 10_000_000 and d["value"] > 1e9
     r = d["roofline"]
-    assert r["bound"] == "fp64_valu_issue" and r["records_advanced"] + r["one_record_launches"] == 1000
-    # frac follows from the line's own numbers
-    want = r["valu_inst_per_wave_record"] * r["waves_per_launch"] * (r["records_advanced"] + r["one_record_launches"]) / \
-        (r["avg_launch_ms"] * 1e-3 * (r["launches"] + r["one_record_launches"])) / 1e9 / r["peak"]
-    assert abs(r["frac"] - want) < 1e-6 * want
-    # round 3: the ceiling weights the instruction classes (4 cycles for the 64-bit ones, 2 for the rest), the instruction count
-    # is the one of THIS run's launch length (fixed per launch + per record), both clocks are stated, and SURVEY's closed-form
-    # bytes charged to every record of a launch come out above the HBM peak (the launch reads state and geometry once)
+    # round 4: the bound is named after what DESIGN 3.2 item 35 found, the share of working lanes is stated next to it, and the
+    # constants behind `frac` are tied to the binary that ran
+    assert r["bound"] == "valu_issue+wave_chain" and r["records_advanced"] + r["one_record_launches"] == 1000
+    assert 0.3 < r["lane_utilisation"] < 0.7 and "crossing-path" in r["lane_utilisation_note"]
+    assert isinstance(r["stale"], bool) and len(r["isa_shipped"]["sha256"]) == 16 and r["isa_shipped"]["static"]["valu"] > 300
+    if r["stale"]:
+        assert r["frac"] is None and r["frac_uniform_4_cycles"] is None and "stale_note" in r
+    else:
+        assert r["isa_profiled"]["sha256"] == r["isa_shipped"]["sha256"]
+        # frac follows from the line's own numbers
+        want = r["valu_inst_per_wave_record"] * r["waves_per_launch"] * (r["records_advanced"] + r["one_record_launches"]) / \
+            (r["avg_launch_ms"] * 1e-3 * (r["launches"] + r["one_record_launches"])) / 1e9 / r["peak"]
+        assert abs(r["frac"] - want) < 1e-6 * want
+        assert r["frac_uniform_4_cycles"] > r["frac"] and r["frac_at_held_clock"] > r["frac"] and 1.5 < r["clock_held_ghz"] <= 2.4
+    # the ceiling weights the instruction classes (4 cycles for the 64-bit ones, 2 for the rest; a model, labelled as one), the
+    # instruction count is the one of THIS run's launch length (fixed per launch + per record), and SURVEY's closed-form bytes
+    # charged to every record of a launch come out above the HBM peak (the launch reads state and geometry once)
     assert 2.0 < r["cycles_per_valu_inst"] < 4.0 and abs(r["peak"] - 1024 * 2.4 / r["cycles_per_valu_inst"]) < 1e-6 * r["peak"]
-    assert r["frac_uniform_4_cycles"] > r["frac"] and r["frac_at_held_clock"] > r["frac"] and 1.5 < r["clock_held_ghz"] <= 2.4
-    assert "fixed per launch" in r["valu_inst_source"] and 190 < r["valu_inst_per_wave_record"] < 230
+    assert "MODEL" in r["peak_note"] and "fixed per launch" in r["valu_inst_source"] and 190 < r["valu_inst_per_wave_record"] < 230
     assert r["hbm"]["survey_formula_frac"] > 1.0 and r["hbm"]["frac"] < 0.5
+    # the Survive derivation inside the clock: every record committed afresh over the box the buoys can touch
+    f = d["fresh_records"]
+    assert "amortised" not in d["note"] and "OUTSIDE the timed region" in d["note"]
+    assert f["records_advanced"] == 1000 and f["launches"] >= 1000 // 32 and 0.3 < f["survive_box_share_of_grid"] < 0.6
+    assert d["value_fresh_records"] == f["value"] and 0.6 * d["value"] < f["value"] < d["value"]
+    assert 3.0 < d["survive_us_per_record"] < 40.0 and abs(f["ms_per_step"] - d["ms_per_step"]) * 1e3 < 4 * d["survive_us_per_record"]
+    # the N = 1 extras: C4's per-rank shard on this GPU and the end-to-end upload segment (whole records and boxes)
+    assert d["c4_shard"]["buoys"] == 12_500_000 and d["c4_shard"]["value"] > 1e10
+    e = d["e2e_upload"]
+    assert e["box"]["upload_bytes_per_step"] < 0.7 * e["whole_record"]["upload_bytes_per_step"] == 0.7 * e["slab_bytes"]
+    assert e["box"]["particle_steps_per_s"] > e["whole_record"]["particle_steps_per_s"] > 1e9
 
 
 @pytest.fixture(scope="module")

@@ -187,6 +187,75 @@ def test_g6b_fast_flow_golden_trajectories(golden, strat, mode):
         trk.close()
 
 
+_CUT_TRK = {}
+
+
+def _cut_tracker(g):
+    """one tracker per BASELINE mesh with the workload's 32 records resident (6.4 GB at 4096^2), shared by the G6c / G6d cases"""
+    from conftest import baseline_cut_case
+    grid, u, v, sic, yx0 = baseline_cut_case(g)
+    key = grid["Yf"].shape
+    if key not in _CUT_TRK:
+        for t in _CUT_TRK.values():
+            t.close()
+        _CUT_TRK.clear()
+        trk = make_tracker(grid, grid["tmask"], u.shape[0], rdt=float(g["rdt"]))
+        for k in range(u.shape[0]):
+            trk.load_record(k, u[k], v[k], sic[k])
+        _CUT_TRK[key] = trk
+    return _CUT_TRK[key], yx0, u.shape[0]
+
+
+@pytest.mark.parametrize("name", ["g6c_c2cut.npz", "g6d_c3cut.npz"])          # (outermost: varies slowest -- one tracker per mesh)
+@pytest.mark.parametrize("mode", ["step", "step_w", "run", "run_unsorted", "run_w", "run_w_unsorted"])
+@pytest.mark.parametrize("strat", [1, 0])
+def test_g6cd_reference_trajectories_on_the_baseline_workloads(golden, name, mode, strat):
+    """G6c / G6d on the device: REFERENCE output on the BASELINE grids themselves -- the first 10^3 buoys x 100 records of bench.py's
+    C2 (512^2) and C3 (4096^2) workloads, 32 resident records cycled, both velocity rules -- record by record with per-record digests
+    (`step`), through fused launches sorted / unsorted (`run`), and -- the case rounds 1-3 tied to the reference only transitively --
+    FUSED LAUNCHES WITH PER-BUOY RECORD WINDOWS (`run_w`: 12 late starters, 12 early stoppers; the launches that cut through a
+    window run the windowed kernel form, the others the plain one), by the final state."""
+    from conftest import traj_digest_row
+    g = golden(name)
+    trk, yx0, K = _cut_tracker(g)
+    kstrt, Nt = int(g["kstrt"]), int(g["Nt"])
+    windows = mode.split("_")[1:2] == ["w"]
+    key = "s%d%s" % (strat, "w" if windows else "")
+    trk.ctx.set_params(float(g["rdt"]), strat, 0.1)
+    win = (g["rec_first"], g["rec_last"]) if windows else (None, None)
+    trk.set_buoys(yx0, g["jiT0"], *win, sort=not mode.endswith("unsorted"))
+    trk.ctx.set_resort(0 if mode.endswith("unsorted") else 24)
+    if mode.startswith("step"):
+        dg = g["digest_" + key]
+        for jt in range(Nt):
+            jrec = jt + kstrt
+            trk.step(jrec, jrec % K)
+            pn, mn = trk.record(jrec)
+            if windows:                                              # the driver pre-writes a late starter's seed position (:289-312)
+                opening = (g["rec_first"] - kstrt) == (jt + 1)
+                pn[opening] = yx0[opening]; mn[opening] = 1
+            st = trk.state()
+            assert np.array_equal(traj_digest_row(pn, mn, st["vJIt"], st["iAlive"]), dg[jt + 1]), jt
+    else:
+        trk.ctx.set_tuning(fuse=32)
+        trk.ctx.launch_stats(reset=True)
+        trk.ctx.run(kstrt % K, kstrt, Nt)
+        ls = trk.ctx.launch_stats()
+        assert ls["fused_records"] + ls["step_launches"] == Nt and ls["fused_launches"] >= 3
+    st = trk.state()
+    assert np.array_equal(st["vJIt"], g["jiT_end_" + key]) and np.array_equal(st["iAlive"], g["alive_end_" + key])
+    assert np.array_equal(st["yx"], g["last_pos_" + key])
+    assert int(g["codes_" + key].sum()) > 0.05 * Nt * len(yx0)
+
+
+def test_g6cd_release_the_shared_trackers():
+    for t in _CUT_TRK.values():
+        t.close()
+    _CUT_TRK.clear()
+    from conftest import _CUT_CACHE
+    _CUT_CACHE.clear()
+
+
 @pytest.mark.parametrize("tag", ["curvi", "regular"])
 @pytest.mark.parametrize("strat", [1, 0])
 @pytest.mark.parametrize("sort", [True, False])

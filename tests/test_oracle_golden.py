@@ -208,6 +208,40 @@ def test_g6b_fast_flow_trajectories_bit_exact(golden, strat):
     assert np.array_equal(tr.alive, g["alive_end_s%d" % strat]) and tr.ncross == int(g["codes_s%d" % strat].sum())
 
 
+@pytest.mark.parametrize("name", ["g6c_c2cut.npz", "g6d_c3cut.npz"])
+def test_g6cd_reference_trajectories_on_the_baseline_workloads(golden, name):
+    """G6c / G6d: the REFERENCE's trajectories on inputs cut from BASELINE configs 2 and 3 themselves -- the first 10^3 buoys x 100
+    records of bench.py's C2 / C3 workloads (same grid, same seeds, the 32 resident records cycled) -- both velocity rules, with and
+    without per-buoy record windows.  The oracle walks them bit for bit: per-record digests, final positions, cells, alive.
+    (The four variants advance in lockstep so that each record is promoted to fp64 once, into buffers that are reused.)"""
+    from conftest import baseline_cut_case, traj_digest_row
+    g = golden(name)
+    grid, u, v, sic, yx0 = baseline_cut_case(g)
+    K, kstrt, Nt = u.shape[0], int(g["kstrt"]), int(g["Nt"])
+    runs = {}
+    for strat in (1, 0):
+        for tag in ("", "w"):
+            kw = dict(rec_first=g["rec_first"], rec_last=g["rec_last"]) if tag else {}
+            runs["s%d%s" % (strat, tag)] = (orc.Tracker(grid, yx0, g["jiT0"].astype(np.int64), rdt=float(g["rdt"]), uv_strategy=strat,
+                                                        nthreads=4, **kw), yx0.copy())
+    bu, bv = np.empty(u.shape[1:]), np.empty(u.shape[1:])
+    bs = np.ones(u.shape[1:])                                       # (siconc is 1 everywhere in the BASELINE fields: checked by the rebuild)
+    for jt in range(Nt):
+        jrec = jt + kstrt
+        np.copyto(bu, u[jrec % K]); np.copyto(bv, v[jrec % K])
+        for key, (tr, last) in runs.items():
+            pn, mn = tr.step(jrec, bu, bv, bs)
+            if key.endswith("w"):                                   # the driver pre-writes a late starter's seed position (:289-312)
+                opening = (g["rec_first"] - kstrt) == (jt + 1)
+                pn[opening] = yx0[opening]; mn[opening] = 1
+            assert np.array_equal(traj_digest_row(pn, mn, tr.jiT, tr.alive), g["digest_" + key][jt + 1]), (key, jt)
+            last[mn == 1] = pn[mn == 1]
+    for key, (tr, last) in runs.items():
+        assert np.array_equal(last, g["last_pos_" + key]) and np.array_equal(tr.jiT, g["jiT_end_" + key]), key
+        assert np.array_equal(tr.alive, g["alive_end_" + key]) and tr.ncross == int(g["codes_" + key].sum()), key
+        assert tr.ncross > 0.05 * Nt * len(yx0)
+
+
 def test_g7_forward_projection_matches_reference_fixture(golden):
     # tools/nc/sitrack_seeding_sidfex_19961215_00_HSS5.nc__KEEP: (lat,lon) f4 -> (y_pos,x_pos) f4 made by the
     # reference's cartopy forward projection from tools/sidfexloc.dat

@@ -9,6 +9,7 @@ ARGS=${@:---steps 128 --warmup 32 --no-cpu-baseline --no-c2 --only-fused}      #
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
+cp sitrack_amd/libsitrk.isa.json "$OUT/" 2>/dev/null || echo "no libsitrk.isa.json (run make -C sitrack_amd/csrc): the profile cannot be tied to the binary"
 echo "== kernel trace" 
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 bench.py $ARGS > "$OUT/kt.log" 2>&1 || { tail -20 "$OUT/kt.log"; exit 1; }
 tail -1 "$OUT/kt.log"

@@ -134,8 +134,14 @@ def main():
                                                         "valu_per_wave_record": res.get("valu_per_wave_record"),
                                                         "records_per_launch": res.get("records_per_launch")}
         prev = (json.load(open(tj)) if os.path.exists(tj) else {}).get(config + "_fused" if fused else config, {})
+        # the fingerprint of the binary that was profiled (tools/profile_gpu.sh copies libsitrk.isa.json next to the traces):
+        # bench.py marks its roofline stale when the library it loaded has another one
+        isa_path = os.path.join(src, "libsitrk.isa.json")
+        if fused and os.path.exists(isa_path):
+            allt[config + "_fused"]["isa"] = json.load(open(isa_path))["kernels"].get("advect_run_kernel<float,1,false>")
         for k in ("valu_per_wave_fixed", "valu_per_wave_per_record", "valu_terms_source", "valu64_frac", "valu64_frac_source",
-                  "salu_per_wave_fixed", "salu_per_wave_per_record"):
+                  "salu_per_wave_fixed", "salu_per_wave_per_record", "valu_main_path_per_wave_record",
+                  "valu_crossing_path_per_wave_record", "valu_paths_source", "crossing_rate"):
             if k in prev:                         # fitted by tools/fit_valu_terms.py from several launch lengths: keep
                 allt[config + "_fused" if fused else config][k] = prev[k]
         json.dump(allt, open(tj, "w"), indent=1)

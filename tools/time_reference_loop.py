@@ -10,6 +10,10 @@ the restatement of the loop body that also generates golden set G6 (the loop liv
 cannot be imported).  Nothing of the reference is copied; only the measured numbers leave the container (BASELINE.md
 section 2, bench.py `cpu_baseline.reference_python`).  The GPU box has no /root/reference: bench.py never calls this.
 
+The trajectories of such a cut are no longer thrown away: `python tests/golden/gen_golden.py g6cd` runs the same loop on the same
+cuts (with the workload's 32 resident records) and commits final states + per-record digests as tests/golden/g6c_c2cut.npz and
+g6d_c3cut.npz, which the oracle (CPU) and the device (step / fused / fused + windows) are held against (round 4).
+
 Same inputs as bench.py: regular 4-km grid, buoys default_rng(1234) in the central 60 %, fields default_rng(2024) with
 umax 0.3 m/s, fp32 records promoted into fp64 arrays once per record like the reference does at :372-374 (three whole-grid
 copies per record: at 4096^2 that copy, not the per-buoy work, dominates a 10^3-buoy sample -- reported both ways).
