@@ -149,6 +149,17 @@ def gather_ranges(local, nP, group=None, dst=0):
     return out
 
 
+class _CudaLayer:
+    """what RecordBroadcaster needs of a device: streams, events, a current-stream scope, pinned host buffers (= torch.cuda)"""
+
+    def __init__(self, torch):
+        self.Stream, self.Event, self.stream = torch.cuda.Stream, torch.cuda.Event, torch.cuda.stream
+        self._torch = torch
+
+    def pinned(self, n, dtype):
+        return self._torch.empty(n, dtype=dtype).pin_memory()
+
+
 class RecordBroadcaster:
     """Delivery of whole records to every rank, overlapped with the stepping (driver `--full-records` under torchrun,
     SURVEY 8e): rank 0 copies the record from pinned host memory into its resident slot on a communication stream,
@@ -157,43 +168,49 @@ class RecordBroadcaster:
     record's Survive mask and steps.  A slot is rewritten only behind the launches that read it.  `deliver()` returns at
     once; the records of the next batch travel while the current batch is stepped with."""
 
-    def __init__(self, ctx, src=0, group=None):
+    def __init__(self, ctx, src=0, group=None, dev=None, slot_view=None):
+        """`dev`: the stream / event layer -- torch.cuda by default; tests hand in a CPU stand-in with the same four names
+        (Stream, Event, stream, and pinned(n, dtype)) so that the slot-recycling protocol runs with a real second rank over gloo.
+        `slot_view(ctx, k)`: the resident slot k as a tensor (default: zero-copy view of the library's device memory)."""
         import torch
         import torch.distributed as dist
         self.ctx, self.src, self.group, self.dist, self.torch = ctx, src, group, dist, torch
+        self.dev = dev if dev is not None else _CudaLayer(torch)
         self.rank = dist.get_rank(group)
-        self.comp, self.comm = torch.cuda.Stream(), torch.cuda.Stream()
+        self.comp, self.comm = self.dev.Stream(), self.dev.Stream()
         ctx.set_stream(self.comp.cuda_stream)
-        self.slots = [slot_tensor(ctx, k) for k in range(ctx.nslots)]
-        self.ready = [torch.cuda.Event() for _ in range(ctx.nslots)]
-        self.free = [torch.cuda.Event() for _ in range(ctx.nslots)]
+        self.slots = [(slot_view or slot_tensor)(ctx, k) for k in range(ctx.nslots)]
+        self.ready = [self.dev.Event() for _ in range(ctx.nslots)]
+        self.free = [self.dev.Event() for _ in range(ctx.nslots)]
         self.pinned = [None, None]                       # two staging buffers on the source rank
-        self.pin_done = [torch.cuda.Event(), torch.cuda.Event()]
+        self.pin_done = [self.dev.Event(), self.dev.Event()]
         self.npush = 0
         for e in self.free:
             e.record(self.comp)
 
     def deliver(self, slot, fields):
         """`fields` = (u, v, sic) on the source rank, None elsewhere"""
-        torch = self.torch
-        with torch.cuda.stream(self.comm):
+        with self.dev.stream(self.comm):
             self.comm.wait_event(self.free[slot])        # the launches that read the slot have finished
             if self.rank == self.src:
                 b = self.npush % 2
                 if self.pinned[b] is None:
-                    self.pinned[b] = torch.empty(self.ctx.slab_elems, dtype=self.slots[slot].dtype).pin_memory()
+                    self.pinned[b] = self.dev.pinned(self.ctx.slab_elems, self.slots[slot].dtype)
                 self.pin_done[b].synchronize()           # the copy that last read this staging buffer is done
                 n = self.ctx.Nj * self.ctx.Ni
                 host = self.pinned[b].numpy()
                 for f, a in enumerate(fields):
                     a = np.asarray(a)
+                    dst = host[f * n:(f + 1) * n]
+                    dst[...] = a.reshape(-1)             # ONE cast, straight into the pinned buffer
                     # the slot's dtype is the context's; a field of another type must survive the cast exactly, as in
-                    # IceTracker.load_record / RecordReader.fields_rows_into (an f8 siconc next to f4 velocities would
-                    # otherwise be rounded silently)
-                    if a.dtype.newbyteorder('=') != host.dtype and not np.array_equal(a.astype(host.dtype).astype(a.dtype), a, equal_nan=True):
-                        raise ValueError("%s is not exactly representable as %s; allocate float64 records"
-                                         % (("u_ice", "v_ice", "siconc")[f], host.dtype))
-                    host[f * n:(f + 1) * n] = a.reshape(-1)
+                    # IceTracker.load_record / RecordReader.fields_box_into (an f8 siconc next to f4 velocities would
+                    # otherwise be rounded silently).  Checked by casting BACK what was just written (no temporary of the
+                    # slot's type): this sits on the critical path of every record, in front of the copy and the broadcast.
+                    if a.dtype.newbyteorder('=') != host.dtype:
+                        if not np.array_equal(dst.astype(a.dtype).reshape(a.shape), a, equal_nan=True):
+                            raise ValueError("%s is not exactly representable as %s; allocate float64 records"
+                                             % (("u_ice", "v_ice", "siconc")[f], host.dtype))
                 self.slots[slot].copy_(self.pinned[b], non_blocking=True)
                 self.pin_done[b].record(self.comm)
                 self.npush += 1

@@ -9,8 +9,10 @@ extra flags `--device`, `--uv-strategy`; under `torchrun` (WORLD_SIZE > 1) the b
 ranks by latitude band and every rank reads only the rows of each record its own buoys can touch (row-band ingest, no
 collective; `--full-records`: rank 0 reads, RCCL broadcast), rank 0 writes the files; errors raise instead of
 `print; exit(0)`; maps need the
-optional `mojito` package and are skipped without it; the full (Nt+1,nP,2) series is only kept in
-host memory when it is written (`-F`) instead of always (the reference's 320 GB at 1e7 buoys x 1000 records).
+optional `mojito` package and are skipped without it; the full (Nt+1,nP,2) series is NEVER held in host memory (the
+reference keeps it twice, si3_part_tracker.py:324-330: 320 GB at 1e7 buoys x 1000 records): with `-F` every record is
+appended to the series file as it is fetched (ncio.CloudBuoysStream: O(nP) memory), `--out-stride K` writes every K-th
+record only, and the always-written 2-record file keeps records 0 and Nt.
 """
 import argparse
 import os
@@ -63,6 +65,9 @@ def parse_args(argv=None):
                     help='under torchrun: every so many records the buoys are re-partitioned over the ranks by their CURRENT host '
                          'row (migration of the states between ranks), so that every rank keeps a compact latitude band to read '
                          '(extra; 0 = never; same results)')
+    ap.add_argument('--out-stride', type=int, default=1,
+                    help='with -F: write every so many-th record of the series only (records 0, K, 2K, ...; extra, default 1 = the '
+                         'reference\'s full series); the records in between go through fused launches of up to K records')
     ap.add_argument('--full-records', action='store_true',
                     help='read and upload whole records (under torchrun: rank 0 reads, RCCL broadcast) instead of only the rows '
                          'each rank\'s buoys can touch (extra; same results)')
@@ -313,16 +318,26 @@ def main(argv=None):
     trk = IceTracker(xYf, xXf, xYu, xXu, xYv, xXv, imaskt, rdt=rdt, iUVstrategy=iUVstrategy, nslots=K, field_dtype=fdt, ctx=ctx)
     trk.set_buoys(xPosC0[mine], vJIt[mine], z1stModelRec[mine] if lUse2DTime else None, zLstModelRec[mine] if lUse2DTime else None)
 
-    # ---- host arrays (rank 0): the full series only when it is written
-    lFull = (not lUse2DTime) or a.plot > 0
+    # ---- outputs (rank 0).  The reference allocates the whole series -- xPosC, xPosG (Nt+1,nP,2) f8, xmask -- and writes it at the
+    #      end (:324-330,515-519).  Here the series file is opened now and every record is appended when it is fetched: host
+    #      memory stays O(nP).  Its time axis is known in advance (record times of the model file).
+    lFull = not lUse2DTime
+    stride = max(1, int(a.out_stride)) if lFull else 1
     vTime = np.zeros(Nt + 1, dtype=int)
+    for jt_ in range(Nt):
+        vTime[jt_] = records.time(jt_ + kstrt) - int(rdt / 2.)
+    vTime[Nt] = vTime[Nt - 1] + int(rdt)
+    corgn = 'NEMO-SI3_' + ModConf + '_' + ModExp
+    series, cf_series = None, None
     if lFull and comm.root:
-        xmask = np.zeros((Nt + 1, nP), dtype='i1')
-        xPosC = np.zeros((Nt + 1, nP, 2)) + FILL
-        xPosG = np.zeros((Nt + 1, nP, 2)) + FILL
-        xPosC[k0, np.arange(nP), :] = xPosC0
-        xPosG[k0, np.arange(nP), :] = xPosG0
-        xmask[k0, np.arange(nP)] = 1
+        cf_series = ('./nc/' + corgn + '_tracking_' + SeedBatch + cdtbin + '_' + date_tag(vTime[0]) + '_' + date_tag(vTime[Nt]) + csfkm
+                     + ('_stride%d' % stride if stride > 1 else '') + '.nc')
+        series = ncio.CloudBuoysStream(cf_series, vTime[::stride], IDs, with_mask=True, corigin=corgn)
+        # record 0: the seeds as the seeding file gave them (:331-333; in 1-D-time mode every window opens at record 0)
+        series.put(0, xPosC0[:, 0], xPosC0[:, 1], xPosG0[:, 0], xPosG0[:, 1], np.ones(nP, dtype='i1'))
+        z2XY, z2GC = np.zeros((2, nP, 2)) + FILL, np.zeros((2, nP, 2)) + FILL
+        zMSK = np.zeros((2, nP), dtype='i1')
+        z2XY[0], z2GC[0], zMSK[0] = xPosC0, xPosG0, 1
     if lUse2DTime:
         ends = set(np.unique(zLstModelRec).tolist())
         if comm.root:
@@ -342,7 +357,8 @@ def main(argv=None):
     #      only (:565-571).  Records are read straight into the library's pinned staging and uploaded on its copy stream
     #      while the previous batch is stepped with; `-F` / `-p` need every record's positions: batches of one.
     def need_output(jrec):
-        return lFull or (lUse2DTime and jrec in ends)
+        k = jrec - kstrt + 1                               # the record of the series this step produces
+        return (lFull and (k % stride == 0 or k == Nt)) or (lUse2DTime and jrec in ends)
 
     bcast = None
     if a.full_records and comm.multi and comm.backend == "nccl":
@@ -355,25 +371,27 @@ def main(argv=None):
             m += 1
         batches.append((jt, m))
         jt += m
-    band = {"jmin": 0, "jmax": -1, "age": None}
+    band = {"box": None, "age": None, "bytes": 0}
+    esz = np.dtype(fdt).itemsize
 
     def upload(jt0, m):
         """records jt0..jt0+m-1 -> slots (jt0+r) % K, asynchronously"""
         t_up = clk.now()
         if not a.full_records:
-            # rows this rank's buoys can touch during those records: the host rows at the last evaluation, widened by one
-            # row per record stepped or queued since (sitrk_buoy_rows waits for the GPU: only every so often)
+            # the box (rows x columns, round 4; rows only before) this rank's buoys can touch during those records: their host
+            # cells at the last evaluation, widened by one cell per record stepped or queued since (sitrk_buoy_box waits for
+            # the GPU: only every so often).  Only that hyperslab of the record is read from the file and uploaded.
             if band["age"] is None or band["age"] + m > 96:
-                band["jmin"], band["jmax"] = ctx.buoy_rows()
+                band["box"] = ctx.buoy_box()
                 band["age"] = 0
-            w = band["age"] + m - 1
-            j0, j1 = (0, 0) if band["jmin"] > band["jmax"] else (max(0, band["jmin"] - 2 - w), min(Nj, band["jmax"] + 3 + w))
+            j0, j1, i0, i1 = ctx.box_of(*band["box"], band["age"] + m - 1)
             band["age"] += m
         for r in range(m):
             jrec, slot = jt0 + r + kstrt, (jt0 + r) % K
             if not a.full_records:
                 if j1 > j0:
-                    ctx.stage_fill(slot, j0, j1 - j0, lambda *outs: records.fields_rows_into(jrec, j0, j1, outs))
+                    ctx.stage_fill(slot, j0, j1 - j0, lambda *outs: records.fields_box_into(jrec, j0, j1, i0, i1, outs), i0=i0, ncols=i1 - i0)
+                    band["bytes"] += 3 * (j1 - j0) * (i1 - i0) * esz
                 else:
                     ctx.commit_record_rows(slot, 0, 0)                  # no live buoy: nothing to read
             elif not comm.multi:
@@ -439,8 +457,6 @@ def main(argv=None):
         upload(*batches[0])
     for ib, (jt0, m) in enumerate(batches):
         jrec0, jrecN = jt0 + kstrt, jt0 + m - 1 + kstrt
-        for r in range(m):
-            vTime[jt0 + r] = records.time(jrec0 + r) - int(rdt / 2.)
         if m == 1:
             nalive = comm.sum_int(trk.alive_count())
             say(' *** record #%d/%d  date = %s   buoys alive = %d' % (jrec0 + 1, Nt0, epoch2clock(vTime[jt0]), nalive))
@@ -461,14 +477,26 @@ def main(argv=None):
         need = need_output(jrec)
         t_f = clk.now()
         if need:
-            pos_l, msk_l = trk.record(jrec)
+            # one record at a time, never the series: xPosC[jt+1], xmask[jt+1] (:459-460) and, for the series, xPosG[jt+1] =
+            # CartNPSkm2Geo1D of that row, FillValue rows included (:493), converted on the device by the rank that owns the rows
+            if lFull:
+                pos_l, msk_l, ll_l = trk.record(jrec, latlon=True)
+                ll = to_caller_order(comm.gather_rows(ll_l, nP))
+            else:
+                pos_l, msk_l = trk.record(jrec)
             pos, msk = to_caller_order(comm.gather_rows(pos_l, nP)), to_caller_order(comm.gather_rows(msk_l, nP))
         if need and comm.root:
             stepped = msk == 1
             if lFull:
-                xPosC[jt + 1, stepped] = pos[stepped]
-                xmask[jt + 1, stepped] = 1
-                xPosG[jt + 1] = ctx.cart2geo(xPosC[jt + 1])
+                k = jt + 1
+                try:
+                    if k % stride == 0:
+                        series.put(k // stride, pos[:, 0], pos[:, 1], ll[:, 0], ll[:, 1], msk)
+                except BaseException:
+                    series.abort()
+                    raise
+                if k == Nt:
+                    z2XY[1], z2GC[1], zMSK[1] = pos, ll, msk
             if lUse2DTime and jrec in ends:
                 sel = np.where(zLstModelRec == jrec)[0]
                 z2XY[1, sel] = pos[sel]
@@ -485,26 +513,25 @@ def main(argv=None):
     if bcast is not None:
         bcast.close()
     clk.add("record_loop_s", t_loop)
+    if not a.full_records:
+        # what box ingest bought, per rank (every rank prints its own line)
+        print(' *** rank %d read and uploaded %.1f MB of the %.1f MB of its %d records (box ingest: the rows x columns its own buoys can touch)'
+              % (comm.rank, band["bytes"] / 1e6, 3.0 * Nj * Ni * esz * Nt / 1e6, Nt), flush=True)
     tk = clk.now()
     records.close()
     launches = ctx.launch_stats()
-    vTime[Nt] = vTime[Nt - 1] + int(rdt)
     state = trk.state()
     vJIt_end, alive_end = to_caller_order(comm.gather_rows(state["vJIt"], nP)), to_caller_order(comm.gather_rows(state["iAlive"], nP))
     trk.close()
     if not comm.root:
         comm.close()
-        return {"rank": comm.rank, "nP": nP, "range": (lo, hi)}
+        return {"rank": comm.rank, "nP": nP, "range": (lo, hi), "upload_bytes": band["bytes"]}
 
     # ---- outputs (:509-571)
-    corgn = 'NEMO-SI3_' + ModConf + '_' + ModExp
     outs = []
     if not lUse2DTime:
-        cf_nc_out = './nc/' + corgn + '_tracking_' + SeedBatch + cdtbin + '_' + date_tag(vTime[0]) + '_' + date_tag(vTime[Nt]) + csfkm + '.nc'
-        ncio.ncSaveCloudBuoys(cf_nc_out, vTime, IDs, xPosC[:, :, 0], xPosC[:, :, 1], xPosG[:, :, 0], xPosG[:, :, 1],
-                              mask=xmask, corigin=corgn)
-        outs.append(cf_nc_out)
-        z2XY = np.stack([xPosC[0], xPosC[Nt]]); z2GC = np.stack([xPosG[0], xPosG[Nt]]); zMSK = np.stack([xmask[0], xmask[Nt]])
+        series.close()                                       # every record is in the file already
+        outs.append(cf_series)
         zTim = []
         zvt = np.array([vTime[0], vTime[Nt]])
     else:
@@ -527,5 +554,5 @@ def main(argv=None):
     clk.t["total_s"] = clk.now() - clk.t0
     comm.close()
     return {"files": outs, "nP": nP, "IDs": IDs, "vJIt": vJIt_end, "iAlive": alive_end, "Nt": Nt, "kstrt": kstrt,
-            "timing": dict(clk.t), "launches": launches,
+            "timing": dict(clk.t), "launches": launches, "upload_bytes": band["bytes"], "record_bytes": 3 * Nj * Ni * esz,
             "rebalances": part.get("rebalances", 0), "migrated": part.get("migrated", 0)}

@@ -454,7 +454,34 @@ class NC4Writer:
         if self.L.H5Dwrite(d, self.L._native[key], 0, 0, 0, a.ctypes.data_as(C.c_void_p)) < 0:
             raise OSError("H5Dwrite(%s) failed" % name)
 
-    def _write_chunks_parallel(self, d, a, chunk, level, fill):
+    def write_rows(self, name, r0, data):
+        """Rows [r0, r0 + len(data)) of a (record, n) variable that was created at its final length (createVariable(nrec=...)):
+        what a streaming writer appends record by record.  Large compressed rows go through the same thread pool + direct chunk
+        writes as write(); small ones through a hyperslab H5Dwrite.  Memory: the rows handed over, until flush()."""
+        d, key, dims = self.vars[name]
+        a = np.ascontiguousarray(data, dtype=np.dtype(key))
+        if a.ndim == len(dims) - 1:
+            a = a[None]
+        lay = self.layout.get(name)
+        if lay is not None and a.ndim == 2 and a.shape[1] >= (1 << 16) and self.L._has_chunk_write and a.dtype.isnative:
+            return self._write_chunks_parallel(d, a, *lay, r0=int(r0))
+        L = self.L
+        nd = a.ndim
+        fsp = L.H5Dget_space(d)
+        st = (hsize_t * nd)(*([int(r0)] + [0] * (nd - 1)))
+        ct = (hsize_t * nd)(*a.shape)
+        msp = L.H5Screate_simple(nd, ct, None)
+        try:
+            if fsp < 0 or msp < 0 or L.H5Sselect_hyperslab(fsp, 0, st, None, ct, None) < 0 or \
+                    L.H5Dwrite(d, L._native[key], msp, fsp, 0, a.ctypes.data_as(C.c_void_p)) < 0:
+                raise OSError("H5Dwrite(%s, rows %d..) failed" % (name, r0))
+        finally:
+            if msp >= 0:
+                L.H5Sclose(msp)
+            if fsp >= 0:
+                L.H5Sclose(fsp)
+
+    def _write_chunks_parallel(self, d, a, chunk, level, fill, r0=0):
         """Shuffle + deflate of every (1 x C) chunk on a thread pool (zlib releases the GIL), raw chunks handed to
         H5Dwrite_chunk: the file is what H5Dwrite's filter pipeline would have produced, in a fraction of the time --
         libhdf5 deflates one chunk after the other on the calling thread, 45 s for the 10^7-buoy files at level 9.
@@ -479,7 +506,7 @@ class NC4Writer:
             self._pending = []
         for r in range(nrec):
             for c0 in range(0, n, cw):
-                self._pending.append((d, r, c0, self._pool.submit(pack, r, c0)))
+                self._pending.append((d, r0 + r, c0, self._pool.submit(pack, r, c0)))
         # every queued job keeps its variable's array alive: bound what waits (10^8 buoys x 2 records x 6 variables = 4.8 GB)
         self._pending_bytes = getattr(self, "_pending_bytes", 0) + a.nbytes
         if self._pending_bytes > int(os.environ.get("SITRK_NC_PENDING_BYTES", str(4 << 30))):

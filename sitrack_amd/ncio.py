@@ -303,14 +303,21 @@ class ModelRecords:
         return tuple(self.f.var(n, (jrec, slice(j0, j1))) for n in names)
 
     def fields_rows_into(self, jrec, j0, j1, outs, names=('u_ice', 'v_ice', 'siconc')):
-        """Rows [j0,j1) of record `jrec` read INTO the arrays `outs` (libsitrk's pinned staging: file -> DMA-able memory
-        in one pass through libhdf5; other backends assign).  Values must survive the cast to the outs' dtype exactly."""
+        """Rows [j0,j1) of record `jrec` read INTO the arrays `outs` (see fields_box_into)"""
+        return self.fields_box_into(jrec, j0, j1, None, None, outs, names)
+
+    def fields_box_into(self, jrec, j0, j1, i0, i1, outs, names=('u_ice', 'v_ice', 'siconc')):
+        """The box rows [j0,j1) x columns [i0,i1) of record `jrec` (what this rank's buoys can touch: the hyperslab of the
+        reference's whole-record reads, si3_part_tracker.py:372-374) read INTO the arrays `outs` (libsitrk's pinned staging:
+        file -> DMA-able memory in one pass through libhdf5; other backends assign).  i0 = i1 = None: whole rows.  Values
+        must survive the cast to the outs' dtype exactly."""
+        index = (jrec, slice(j0, j1)) if i0 is None else (jrec, slice(j0, j1), slice(i0, i1))
         for n, out in zip(names, outs):
             packed = self.f.has_attr(n, 'scale_factor') or self.f.has_attr(n, 'add_offset')
             if self.f.h5 is not None and not packed and self.f.h5.dtype(n).itemsize <= out.dtype.itemsize:
-                self.f.h5.read(n, (jrec, slice(j0, j1)), out=out)
+                self.f.h5.read(n, index, out=out)
                 continue
-            a = np.asarray(self.f.var(n, (jrec, slice(j0, j1))))
+            a = np.asarray(self.f.var(n, index))
             if a.dtype.newbyteorder('=') != out.dtype and not np.array_equal(a.astype(out.dtype).astype(a.dtype), a, equal_nan=True):
                 raise ValueError("%s is not exactly representable as %s; allocate float64 records" % (n, out.dtype))
             out[...] = a
@@ -404,11 +411,12 @@ def ncSaveCloudBuoys(cf_out, ptime, pIDs, pY, pX, pLat, pLon, mask=[], xtime=[],
     return 0
 
 
-def _save_nc4_hdf5(cf_out, ptime, pIDs, pY, pX, pLat, pLon, mask, xtime, tunits, fillVal, corigin, about, author):
-    """ncSaveCloudBuoys without the netCDF4 package: the same NetCDF-4 file (reference ncio.py:143-195 -- dimensions,
-    variable types, `_FillValue`, shuffle + deflate at level 9, units, global attributes) written through libhdf5."""
+def _nc4_hdf5_create(cf_out, Nt, pIDs, with_mask, with_xtime, tunits, fillVal, corigin, about, author):
+    """The NetCDF-4 file of ncSaveCloudBuoys without the netCDF4 package (reference ncio.py:143-195 -- dimensions, variable types,
+    `_FillValue`, shuffle + deflate at level 9, units, global attributes), created at its final length of Nt records through
+    libhdf5; the record variables are still to be written.  Returns the open h5lite.NC4Writer."""
     from . import h5lite
-    Nt, Nb = len(ptime), len(pIDs)
+    Nb = len(pIDs)
     lvl = int(os.environ.get('SITRK_NC_COMPLEVEL', '9'))          # the reference's complevel; lower it for 10^7-buoy files
     w = h5lite.NC4Writer(cf_out)
     try:
@@ -420,9 +428,9 @@ def _save_nc4_hdf5(cf_out, ptime, pIDs, pY, pX, pLat, pLon, mask, xtime, tunits,
         kw = dict(fill_value=fillVal, zlib=True, complevel=lvl, nrec=Nt)
         for name in ('latitude', 'longitude', 'y_pos', 'x_pos'):
             w.createVariable(name, 'f4', ('time', 'buoy'), **kw)
-        if mask is not None:
+        if with_mask:
             w.createVariable('mask', 'i1', ('time', 'buoy'), zlib=True, complevel=lvl, nrec=Nt)
-        if xtime is not None:
+        if with_xtime:
             w.createVariable('time_pos', 'i4', ('time', 'buoy'), **kw)
         w.set_attr('time', 'units', tunits)
         w.set_attr('id_buoy', 'units', 'ID of buoy')
@@ -430,10 +438,24 @@ def _save_nc4_hdf5(cf_out, ptime, pIDs, pY, pX, pLat, pLon, mask, xtime, tunits,
         w.set_attr('longitude', 'units', 'degrees south')
         w.set_attr('y_pos', 'units', 'km')
         w.set_attr('x_pos', 'units', 'km')
-        if xtime is not None:
+        if with_xtime:
             w.set_attr('time_pos', 'units', tunits)
         w.write('buoy', np.arange(Nb, dtype='i4'))
         w.write('id_buoy', np.asarray(pIDs, dtype=np.int64))
+        if corigin:
+            w.set_global('Origin', corigin)
+        w.set_global('About', about)
+        w.set_global('Author', author)
+    except BaseException:
+        w.abort()                       # ids closed, partial file removed; never raises: the original error is the one seen
+        raise
+    return w
+
+
+def _save_nc4_hdf5(cf_out, ptime, pIDs, pY, pX, pLat, pLon, mask, xtime, tunits, fillVal, corigin, about, author):
+    """ncSaveCloudBuoys without the netCDF4 package: the same NetCDF-4 file written through libhdf5, whole arrays at once."""
+    w = _nc4_hdf5_create(cf_out, len(ptime), pIDs, mask is not None, xtime is not None, tunits, fillVal, corigin, about, author)
+    try:
         w.write('time', np.asarray(ptime).astype('i4'))
         w.write('latitude', np.asarray(pLat, dtype=np.float32))
         w.write('longitude', np.asarray(pLon, dtype=np.float32))
@@ -443,12 +465,107 @@ def _save_nc4_hdf5(cf_out, ptime, pIDs, pY, pX, pLat, pLon, mask, xtime, tunits,
             w.write('mask', np.asarray(mask, dtype='i1'))
         if xtime is not None:
             w.write('time_pos', np.asarray(xtime).astype('i4'))
-        if corigin:
-            w.set_global('Origin', corigin)
-        w.set_global('About', about)
-        w.set_global('Author', author)
     except BaseException:
-        w.abort()                       # ids closed, partial file removed; never raises: the original error is the one seen
+        w.abort()
         raise
     w.close()
     return 0
+
+
+class CloudBuoysStream:
+    """ncSaveCloudBuoys RECORD BY RECORD: the same file (reference ncio.py:131-197, which itself writes record by record inside its
+    loop :176-190 -- after having held the whole (Nt+1, nP, 2) series in memory twice, si3_part_tracker.py:324-330), fed while the
+    records are produced, so that the writer's memory is O(nP) whatever the number of records: the `-F` series of 1e7 buoys x
+    thousands of records is 0.3-1 TB as arrays.  The time axis is known in advance (`ptime`, all Nt output records); `put(k, ...)`
+    casts record k to the file's types and hands it to the backend (libhdf5 through h5lite: rows deflated on a thread pool and
+    written as raw chunks, flushed every `flush_bytes`; netCDF4 or the NetCDF-3 fall-back: one record slice per variable)."""
+
+    def __init__(self, cf_out, ptime, pIDs, with_mask=True, tunits=tunits_default, fillVal=FillValue, corigin=None,
+                 cauthor='si3_part_tracker.py', flush_bytes=256 << 20):
+        from . import h5lite
+        self.path, self.Nt, self.Nb = cf_out, len(ptime), len(pIDs)
+        self.with_mask, self.nput = with_mask, 0
+        os.makedirs(path.dirname(cf_out) or '.', exist_ok=True)
+        about = 'Lagrangian sea-ice drift'
+        author = 'Generated with `' + cauthor + '` of `sitrack` (L. Brodeau, 2023)'
+        self.w = self.f = None
+        if _nc4 is None and h5lite.writer_available():
+            self.w = _nc4_hdf5_create(cf_out, self.Nt, pIDs, with_mask, False, tunits, fillVal, corigin, about, author)
+            self.flush_bytes, self.queued = int(flush_bytes), 0
+            self.w.write('time', np.asarray(ptime).astype('i4'))
+            return
+        if _nc4 is not None:
+            f = _nc4.Dataset(cf_out, 'w', format='NETCDF4')
+            kw = dict(fill_value=fillVal, zlib=True, complevel=9)
+        else:
+            from scipy.io import netcdf_file
+            f = netcdf_file(cf_out, 'w', version=2)
+            kw = {}
+            if np.any(np.abs(np.asarray(pIDs, dtype=np.int64)) > 2 ** 53):
+                raise ValueError('CloudBuoysStream: a buoy ID beyond 2^53 cannot be stored by the NetCDF-3 fall-back writer')
+        f.createDimension('time', None)
+        f.createDimension('buoy', self.Nb)
+        v_time = f.createVariable('time', 'i4', ('time',))
+        v_buoy = f.createVariable('buoy', 'i4', ('buoy',))
+        v_bid = f.createVariable('id_buoy', 'i8' if _nc4 is not None else 'f8', ('buoy',))
+        self.v = {n: f.createVariable(n, 'f4', ('time', 'buoy'), **kw) for n in ('latitude', 'longitude', 'y_pos', 'x_pos')}
+        if with_mask:
+            self.v['mask'] = f.createVariable('mask', 'i1', ('time', 'buoy'), **({'zlib': True, 'complevel': 9} if _nc4 is not None else {}))
+        if _nc4 is None:
+            for n in ('latitude', 'longitude', 'y_pos', 'x_pos'):
+                self.v[n]._FillValue = np.float32(fillVal)
+        v_time.units = tunits
+        v_bid.units = 'ID of buoy'
+        for n, un in (('latitude', 'degrees north'), ('longitude', 'degrees south'), ('y_pos', 'km'), ('x_pos', 'km')):
+            self.v[n].units = un
+        v_buoy[:] = np.arange(self.Nb, dtype='i4')
+        v_bid[:] = np.asarray(pIDs)[:]
+        v_time[:] = np.asarray(ptime).astype('i4')
+        if corigin:
+            f.Origin = corigin
+        f.About = about
+        f.Author = author
+        self.f = f
+
+    def put(self, k, pY, pX, pLat, pLon, mask=None):
+        """record k of the file (0 <= k < Nt): (nP,) arrays"""
+        if not (0 <= k < self.Nt):
+            raise IndexError("record %d outside the %d records of %s" % (k, self.Nt, self.path))
+        rows = {'latitude': np.asarray(pLat, dtype=np.float32), 'longitude': np.asarray(pLon, dtype=np.float32),
+                'y_pos': np.asarray(pY, dtype=np.float32), 'x_pos': np.asarray(pX, dtype=np.float32)}
+        if self.with_mask:
+            rows['mask'] = np.asarray(mask, dtype='i1')
+        for n, r in rows.items():
+            if r.shape != (self.Nb,):
+                raise ValueError('CloudBuoysStream.put: %s has shape %s, expected (%d,)' % (n, r.shape, self.Nb))
+            if self.w is not None:
+                self.w.write_rows(n, k, r[None, :])
+                self.queued += r.nbytes
+            else:
+                self.v[n][k, :] = r
+        if self.w is not None and self.queued >= self.flush_bytes:
+            self.w.flush()
+            self.queued = 0
+        self.nput += 1
+
+    def close(self):
+        if self.nput != self.Nt:
+            self.abort()
+            raise ValueError('%s: %d of %d records were written' % (self.path, self.nput, self.Nt))
+        if self.w is not None:
+            self.w.close()
+        else:
+            self.f.close()
+        self.w = self.f = None
+
+    def abort(self):
+        """give up on the file (an error on the way): ids closed, the partial file removed; never raises"""
+        try:
+            if self.w is not None:
+                self.w.abort()
+            elif self.f is not None:
+                self.f.close()
+                os.remove(self.path)
+        except Exception:               # noqa: BLE001
+            pass
+        self.w = self.f = None

@@ -288,6 +288,164 @@ def test_world2_gloo_partition_broadcast_gather():
     assert ncross > 100
 
 
+class _CpuLayer:
+    """Stand-in for torch.cuda in RecordBroadcaster: the host is the device, work runs when it is queued.  Events carry the
+    sequence number of their last record(), so the test can audit WHAT each wait fences (the protocol), while the slot contents
+    show that the right bytes were there when they were stepped with."""
+
+    def __init__(self, torch):
+        self._torch, self.seq, self.log = torch, 0, []
+        layer = self
+
+        class Stream:
+            cuda_stream = None
+
+            def wait_event(self, e):
+                assert e.seq is not None, "wait on an event that was never recorded"
+                layer.log.append(("wait", e.seq))
+                self.last_waited = e.seq
+
+            def synchronize(self):
+                pass
+
+        class Event:
+            seq = None
+
+            def record(self, stream=None):
+                layer.seq += 1
+                self.seq = layer.seq
+
+            def synchronize(self):
+                pass
+
+        self.Stream, self.Event = Stream, Event
+
+    def tick(self):
+        self.seq += 1
+        return self.seq
+
+    def stream(self, s):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def pinned(self, n, dtype):
+        return self._torch.empty(n, dtype=dtype)
+
+
+class _FakeCtx:
+    """what RecordBroadcaster touches of a sitrack_amd Context: slots, their geometry, the in-place-write / commit protocol"""
+
+    def __init__(self, torch, nslots, Nj, Ni):
+        self.nslots, self.Nj, self.Ni, self.slab_elems = nslots, Nj, Ni, 3 * Nj * Ni
+        self.mem = [torch.full((self.slab_elems,), float("nan"), dtype=torch.float32) for _ in range(nslots)]
+        self.dirty = [False] * nslots
+        self.committed = [None] * nslots                 # checksum of the slab at its last commit
+        self.stream = "own"
+
+    def set_stream(self, s):
+        self.stream = s
+
+    def record_ptr(self, slot):
+        self.dirty[slot] = True
+
+    def commit_record(self, slot):
+        assert self.dirty[slot], "commit of a slot nobody wrote"
+        self.dirty[slot] = False
+        self.committed[slot] = float(self.mem[slot].double().sum())
+
+
+def _bcaster_worker(rank, world, port, q):
+    """RecordBroadcaster with a real second rank (gloo) and its stream / event layer on the CPU: 13 records through 4 slots in
+    batches of 2, every slot rewritten three times while the protocol decides when."""
+    import torch
+    import torch.distributed as dist
+    from sitrack_amd import distributed as sd
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        Nj, Ni, S, Nrec, m = 6, 10, 4, 13, 2
+        n = Nj * Ni
+        rng = np.random.default_rng(3)
+        recs = [tuple(rng.integers(-99, 99, (Nj, Ni)).astype(np.float64) * 0.25 for _ in range(3)) for _ in range(Nrec)]   # exact in f4
+        ctx = _FakeCtx(torch, S, Nj, Ni)
+        dev = _CpuLayer(torch)
+        bc = sd.RecordBroadcaster(ctx, src=0, dev=dev, slot_view=lambda c, k: c.mem[k])
+        assert ctx.stream is None                         # the library's stream was handed over to the layer's compute stream
+        last_read, last_write, holds = [0] * S, [0] * S, [None] * S
+        ok = True
+
+        def deliver(jt):
+            slot = jt % S
+            bc.deliver(slot, recs[jt] if rank == 0 else None)
+            # the write waited for an event recorded AFTER the last launch that read the slot ...
+            nonlocal ok
+            ok = ok and bc.comm.last_waited > last_read[slot]
+            last_write[slot] = bc.ready[slot].seq
+            holds[slot] = jt
+
+        def run(jt0, cnt):
+            nonlocal ok
+            used = [(jt0 + r) % S for r in range(cnt)]
+            bc.before_run(used)
+            for r, slot in enumerate(used):
+                # ... the launch waited for the slot's delivery, committed it, and the slot holds the record it is stepped with
+                want = np.concatenate([a.reshape(-1) for a in recs[jt0 + r]]).astype(np.float32)
+                ok = ok and holds[slot] == jt0 + r and bc.ready[slot].seq >= last_write[slot] and not ctx.dirty[slot]
+                ok = ok and np.array_equal(ctx.mem[slot].numpy(), want) and ctx.committed[slot] == float(want.astype(np.float64).sum())
+                last_read[slot] = dev.tick()
+            bc.after_run(used)
+            for slot in used:
+                ok = ok and bc.free[slot].seq > last_read[slot]
+
+        batches = [(j, min(m, Nrec - j)) for j in range(0, Nrec, m)]
+        for r in range(batches[0][1]):
+            deliver(r)
+        for ib, (jt0, cnt) in enumerate(batches):
+            if ib + 1 < len(batches):                   # the next batch travels "while" this one is stepped with
+                for r in range(batches[ib + 1][1]):
+                    deliver(batches[ib + 1][0] + r)
+            run(jt0, cnt)
+        # a field that does not survive the cast to the slot's type is refused on the source rank, before anything is sent
+        if rank == 0:
+            bad = list(recs[0]); bad[2] = bad[2] + 1e-9
+            try:
+                bc.deliver(0, tuple(bad))
+                ok = False
+            except ValueError as e:
+                ok = ok and "siconc is not exactly representable" in str(e)
+        bc.close()
+        ok = ok and ctx.stream is None
+        t = torch.tensor([1 if ok else 0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            q.put("ok" if int(t[0]) == 1 else "protocol or contents wrong on some rank")
+    except Exception as e:                                # noqa: BLE001
+        if rank == 0:
+            q.put("rank 0: %r" % (e,))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_record_broadcaster_slot_recycling_world2_gloo():
+    """`RecordBroadcaster` (distributed.py) -- pinned staging -> slot on a communication stream, broadcast in
+    place, the compute stream ordered behind the slot's event only, slots recycled behind the launches that read them -- had only
+    ever run with ONE rank.  Here its stream / event layer is a CPU stand-in and the broadcast is a real gloo broadcast between
+    two processes: the slot-recycling logic runs with a second rank, contents and fences audited on both."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bcaster_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    status = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert status == "ok", status
+
+
 @pytest.mark.gpu
 def test_slot_tensor_broadcast_world1_rccl():
     """RCCL path on one GPU: the broadcast writes the resident slot in place."""
@@ -400,6 +558,14 @@ def test_bench_two_ranks_as_the_driver_launches_it():
     vr = rc["value_per_rank"]
     assert len(vr["all"]) == 2 and 0 < vr["min"] <= vr["max"] and d["value"] <= 2 * vr["min"] * (1 + 1e-9)
     assert "degraded" not in d
+    # round 4: the curve is readable before it is run -- the same-shard N = 1 point is measured in THIS job (rank 0 alone, the
+    # other rank idle at a barrier) and the line carries the ratio; the fresh-records leg runs on every rank
+    so = d["solo_same_shard"]
+    assert so["value"] > 0 and so["launches"] >= 1
+    assert abs(d["efficiency_vs_n1_same_shard"] - d["value"] / (2 * so["value"])) < 1e-9
+    assert 0.2 < d["efficiency_vs_n1_same_shard"] < 1.5          # (two ranks share ONE GPU here: anything but a scaling figure)
+    assert d["fresh_records"]["records_advanced"] == 40 and d["value_fresh_records"] > 0
+    assert "c4_shard" not in d and "e2e_upload" not in d          # the N = 1 extras stay out of the N > 1 line
 
 
 @pytest.mark.gpu
@@ -422,6 +588,7 @@ def test_bench_multi_gpu_code_path_with_one_rccl_rank():
     rc = d["rccl"]
     assert rc["world"] == 1 and rc["backend"].startswith("rccl") and rc["ranks"][0]["rank"] == 0 and rc["distinct_devices"] == 1
     assert rc["slab_checksum_ok"] is True and rc["slab_checksum_matches_source"] is True and "degraded" not in d
+    assert d["solo_same_shard"]["value"] > 0 and 0.5 < d["efficiency_vs_n1_same_shard"] < 1.5      # one rank: the two legs are the same run
     e = d["e2e_broadcast"]
     assert "error" not in e, e
     for mode in ("broadcast", "scatter_allgather"):

@@ -5,6 +5,7 @@ import os
 import numpy as np
 import pytest
 
+import sitrack_amd as sit
 from sitrack_amd import driver as drv
 from sitrack_amd import ncio
 from sitrack_amd import synthetic as syn
@@ -513,6 +514,75 @@ def test_cli_end_to_end_vs_oracle(tmp_path, monkeypatch, two_d_time):
     # second run hits the seed cache and reproduces the same result
     out2 = drv.main(argv)
     assert np.array_equal(out2["vJIt"], out["vJIt"]) and np.array_equal(out2["iAlive"], out["iAlive"])
+
+
+@pytest.mark.gpu
+def test_cli_F_streams_the_series_in_bounded_memory_and_out_stride(tmp_path, monkeypatch):
+    """`-F` at a size where the reference's way would not fit a laptop: >= 1e6 buoys x 200 hourly records.  The reference holds the
+    whole series twice as (Nt+1, nP, 2) f8 arrays (si3_part_tracker.py:324-330: 6.7 GB here, 0.3-1 TB at 1e7 buoys x thousands of
+    records) and writes it at the end (:515-519); the driver appends every record to the file as it is fetched.  Checked:
+    (1) the command line's peak resident memory stays below 2 GB (own process, measured by itself); (2) the file equals, variable for
+    variable, the one the in-memory writer (ncSaveCloudBuoys on whole arrays) makes of an independent run of the same tracking;
+    (3) `--out-stride 8`: the records in between go through fused launches and the file holds every 8th record of the `-F` file."""
+    import json
+    import subprocess
+    import sys
+    monkeypatch.chdir(tmp_path)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    Nrec = 200
+    c = make_case(str(tmp_path), nrec=Nrec, nP=1_150_000)
+    launcher = ("import json, resource, sys; sys.path.insert(0, %r); from sitrack_amd import driver as drv; "
+                "out = drv.main(sys.argv[1:]); "
+                "print('RESULT ' + json.dumps({'files': out['files'], 'nP': int(out['nP']), 'launches': out['launches'], "
+                "'maxrss_kb': resource.getrusage(resource.RUSAGE_SELF).ru_maxrss}))" % root)
+    res = {}
+    for tag, extra in (("full", []), ("stride", ["--out-stride", "8"])):
+        r = subprocess.run([sys.executable, "-c", launcher, "-i", c["si3"], "-m", c["mm"], "-s", c["seed"], "-N", "TEST4", "-F"] + extra,
+                           capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        res[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    nP = res["full"]["nP"]
+    assert nP >= 1_000_000
+    series_bytes = 2 * (Nrec + 1) * nP * 2 * 8
+    assert series_bytes > 6e9
+    for tag in res:
+        assert res[tag]["maxrss_kb"] < 2 * 1024 * 1024, (tag, res[tag]["maxrss_kb"])          # (1)
+    assert res["full"]["launches"]["step_launches"] == Nrec                                 # every record fetched: batches of one
+    assert res["stride"]["launches"]["fused_launches"] == Nrec // 8 and res["stride"]["launches"]["fused_records"] == Nrec
+    f_full, f_12 = res["full"]["files"]
+    assert res["stride"]["files"][0] == f_full.replace(".nc", "_stride8.nc") and res["stride"]["files"][1] == f_12
+    # (2) an independent run of the same tracking, the series held in memory like the reference does, written at once
+    with np.load("./seed/Initialized_buoys_sitrack_seeding_nemoTsi3_19961215_00_HSS5_TEST4.npz") as z:
+        xPosG0, xPosC0, IDs, vJIt = z["xPosG0"], z["xPosC0"], z["IDs"], z["vJIt"]
+    imaskt, _, _, _, _, xYf, xXf, _ = ncio.GetModelGrid(c["mm"])
+    xYv, xXv, xYu, xXu = ncio.GetModelUVGrid(c["mm"])
+    trk = sit.IceTracker(xYf, xXf, xYu, xXu, xYv, xXv, imaskt, nslots=2)
+    trk.set_buoys(xPosC0, vJIt)
+    xPosC = np.zeros((Nrec + 1, nP, 2)) + drv.FILL; xPosG = np.zeros((Nrec + 1, nP, 2)) + drv.FILL
+    xmask = np.zeros((Nrec + 1, nP), dtype='i1')
+    xPosC[0], xPosG[0], xmask[0] = xPosC0, xPosG0, 1
+    for jt in range(Nrec):
+        trk.load_record(jt % 2, c["u"][jt], c["v"][jt], c["sic"][jt])
+        trk.step(jt, jt % 2)
+        pos, msk = trk.record(jt)
+        xPosC[jt + 1, msk == 1] = pos[msk == 1]; xmask[jt + 1, msk == 1] = 1
+        xPosG[jt + 1] = trk.ctx.cart2geo(xPosC[jt + 1])                               # :493
+    trk.close()
+    assert 0 < (xmask[Nrec] == 0).sum() < nP
+    vTime = c["base"] + 3600 * np.arange(Nrec + 1)
+    ncio.ncSaveCloudBuoys("./nc/in_memory.nc", vTime, IDs, xPosC[:, :, 0], xPosC[:, :, 1], xPosG[:, :, 0], xPosG[:, :, 1], mask=xmask,
+                          corigin='NEMO-SI3_TEST4_EXP01')
+    from sitrack_amd import h5lite
+    for f, rows in ((f_full, slice(None)), (res["stride"]["files"][0], slice(None, None, 8))):
+        a, b = h5lite.H5File("./nc/in_memory.nc"), h5lite.H5File(f)
+        for name in ("time", "buoy", "id_buoy", "latitude", "longitude", "y_pos", "x_pos", "mask"):
+            va, vb = a.read(name), b.read(name)
+            want = va if name in ("buoy", "id_buoy") else va[rows]
+            assert want.dtype == vb.dtype and np.array_equal(want, vb), (f, name)
+            if name in ("time", "latitude"):
+                assert a.attr(name, "units") == b.attr(name, "units")
+        a.close(); b.close()
+    assert (Nrec // 8 + 1) == h5lite.H5File(res["stride"]["files"][0]).shape("time")[0]
 
 
 @pytest.mark.gpu
