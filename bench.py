@@ -1019,7 +1019,9 @@ def main():
             rec_s = (ev_ms_total / 1e3) / max(nr + ns, 1)
             A = 50.0 * nP + 48.0 * n_cells + 8.0 * n_cells * rpl          # bytes one launch of rpl records needs
             w64 = prof_fused.get("valu64_frac")
-            cpi = 4.0 * w64 + 2.0 * (1.0 - w64) if w64 is not None else 4.0
+            mb = prof.get("valu_issue_microbench", {})
+            c64, c32 = mb.get("cycles_64bit", 4.0), mb.get("cycles_32bit", 2.0)       # measured issue cost per wave64 instruction per SIMD
+            cpi = c64 * w64 + c32 * (1.0 - w64) if w64 is not None else 4.0
             peak = 1024 * 2.4 / cpi
             held = prof_fused.get("sclk_ghz")
             shipped, profiled = isa_fingerprint(), prof_fused.get("isa")
@@ -1032,9 +1034,11 @@ def main():
                    "records_per_launch": rpl, "avg_launch_ms": launch_ms, "waves_per_launch": nwaves,
                    "valu_inst_per_wave_record": ipwr, "valu_inst_source": ipwr_src,
                    "valu64_class_share": w64, "cycles_per_valu_inst": cpi,
-                   "peak_note": "a MODEL: 1024 SIMDs x 2.4 GHz / (4 cycles x share of 64-bit-class VALU instructions + %s cycles x the rest); "
-                                "peak_uniform_4_cycles prices every wave64 VALU instruction at 4 cycles (%s)"
-                                % ("2", prof.get("valu_issue_microbench", {}).get("summary", "32-bit issue cost not pinned by a microbenchmark yet")),
+                   "cycles_64bit_class": c64, "cycles_32bit_class": c32,
+                   "peak_note": "a MODEL built on measured issue costs: 1024 SIMDs x 2.4 GHz / (%.2f cycles x share of 64-bit-class VALU "
+                                "instructions + %.2f cycles x the rest); peak_uniform_4_cycles prices every wave64 VALU instruction at 4 cycles.  %s"
+                                % (c64, c32, mb.get("summary", "issue costs not pinned by a microbenchmark: nominal 4 / 2 cycles")),
+                   "peak_source": mb.get("source"),
                    "peak_uniform_4_cycles": VALU_PEAK_GINST,
                    "stale": stale, "isa_shipped": shipped, "isa_profiled": profiled}
             # share of the issued lanes that do work: the main path runs with all 64 lanes, the crossing path -- every wave, every

@@ -528,6 +528,7 @@ def test_cli_F_streams_the_series_in_bounded_memory_and_out_stride(tmp_path, mon
     import subprocess
     import sys
     monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("SITRK_NC_COMPLEVEL", "1")       # (three 5-GB series are deflated here: the reference's level 9 is tested elsewhere)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     Nrec = 200
     c = make_case(str(tmp_path), nrec=Nrec, nP=1_150_000)
