@@ -106,6 +106,41 @@ def scatter_allgather(t, src=0, group=None):
     return t
 
 
+def union_box(box, Nj, Ni, group=None, device=None):
+    """The smallest box that contains every rank's box (j0, j1, i0, i1) (empty boxes -- j0 == j1 -- do not count): what ONE
+    broadcast has to carry so that every rank finds the cells its own buoys can touch.  One all-reduce of four integers."""
+    import torch
+    import torch.distributed as dist
+    j0, j1, i0, i1 = box
+    empty = j1 <= j0 or i1 <= i0
+    t = torch.tensor([-(Nj if empty else j0), 0 if empty else j1, -(Ni if empty else i0), 0 if empty else i1], dtype=torch.int64,
+                     device=device or ("cuda" if dist.get_backend(group) == "nccl" else "cpu"))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    j0, j1, i0, i1 = -int(t[0]), int(t[1]), -int(t[2]), int(t[3])
+    return (0, 0, 0, 0) if (j1 <= j0 or i1 <= i0) else (j0, j1, i0, i1)
+
+
+def broadcast_box(slot_t, Nj, Ni, box, buf, src=0, group=None):
+    """ONE broadcast of the box rows [j0,j1) x columns [i0,i1) of a record's three fields instead of the whole [u|v|siconc] slab:
+    the source packs the box out of its slot `slot_t` (1-D, 3*Nj*Ni) into the contiguous buffer `buf`, the broadcast moves
+    3*(j1-j0)*(i1-i0) elements, every other rank unpacks them into its own slot (strided device copies on the current stream).
+    The rest of the receivers' slots keeps what it held: commit the slot with sitrk_commit_record_box(box)."""
+    import torch.distributed as dist
+    j0, j1, i0, i1 = box
+    nr, nc = j1 - j0, i1 - i0
+    if nr <= 0 or nc <= 0:
+        return 0
+    view = slot_t.view(3, Nj, Ni)[:, j0:j1, i0:i1]
+    flat = buf[:3 * nr * nc]
+    packed = flat.view(3, nr, nc)
+    if dist.get_rank(group) == src:
+        packed.copy_(view)
+    dist.broadcast(flat, src=src, group=group)
+    if dist.get_rank(group) != src:
+        view.copy_(packed)
+    return flat.numel() * flat.element_size()
+
+
 def broadcast_record_host(slab_host, nelem, dtype, src=0, group=None):
     """gloo rehearsal of the same exchange on host memory: returns the slab on every rank."""
     import torch

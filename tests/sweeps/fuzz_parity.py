@@ -68,7 +68,36 @@ def one_case(rng, idx, nstrat=2):
     for k in range(K):
         trk.load_record(k, u[k], v[k], sic[k])
     j0 = int(rng.integers(0, 5))
-    if fuse == 1 and rng.random() < 0.5:
+    boxed = rng.random() < 0.35
+    if boxed:
+        # round 4: records arrive as BOXES (rows x columns the buoys can touch), everything else of the slot poisoned; a third of the
+        # boxed cases commit the box of a slab that sits in device memory whole (commit_records_box, one Survive launch per batch)
+        poison = (np.full((Nj, Ni), np.nan, dtype=fdt), np.full((Nj, Ni), np.nan, dtype=fdt), np.zeros((Nj, Ni), dtype=fdt))
+        commit = rng.random() < 0.33
+        m = max(1, min(fuse, K))
+        s = 0
+        while s < Nt:
+            cnt = min(m, Nt - s)
+            box = trk.ctx.box(cnt - 1)
+            for r in range(cnt):
+                k = (j0 + s + r) % K
+                if commit:
+                    comp = [p_.copy() for p_ in poison]
+                    for dst, src in zip(comp, (u[k], v[k], sic[k])):
+                        dst[box[0]:box[1], box[2]:box[3]] = src[box[0]:box[1], box[2]:box[3]]
+                    trk.ctx.push_record(k, *comp)
+                else:
+                    trk.ctx.push_record(k, *poison)
+                    if box[1] > box[0]:
+                        trk.ctx.push_record_box(k, *box, u[k][box[0]:box[1], box[2]:box[3]], v[k][box[0]:box[1], box[2]:box[3]],
+                                                sic[k][box[0]:box[1], box[2]:box[3]])
+            if commit:
+                trk.ctx.commit_records_box((j0 + s) % K, cnt, *box)
+            trk.ctx.run((j0 + s) % K, j0 + s, cnt)
+            for r in range(cnt):
+                ref.step(j0 + s + r, u[(j0 + s + r) % K], v[(j0 + s + r) % K], sic[(j0 + s + r) % K], want_out=False)
+            s += cnt
+    elif fuse == 1 and rng.random() < 0.5:
         for s in range(Nt):
             trk.step(j0 + s, (j0 + s) % K)
             rp, rm = ref.step(j0 + s, u[(j0 + s) % K], v[(j0 + s) % K], sic[(j0 + s) % K])
@@ -84,8 +113,8 @@ def one_case(rng, idx, nstrat=2):
     assert np.array_equal(st["vJIt"], ref.jiT), ("cell", idx)
     assert np.array_equal(st["iAlive"], ref.alive), ("alive", idx)
     assert np.array_equal(st["kill_rec"] >= 0, ref.alive == 0), ("kill_rec", idx)
-    desc = "grid %dx%d warp %.1f dkm %.1f nP %d Nt %d K %d strat %d %s win %d fuse %d tile %d: crossings %d dead %d" % (
-        Nj, Ni, warp, dkm, n, Nt, K, strat, np.dtype(fdt).name, windowed, fuse, tile, ref.ncross, int((ref.alive == 0).sum()))
+    desc = "grid %dx%d warp %.1f dkm %.1f nP %d Nt %d K %d strat %d %s win %d fuse %d tile %d box %d: crossings %d dead %d" % (
+        Nj, Ni, warp, dkm, n, Nt, K, strat, np.dtype(fdt).name, windowed, fuse, tile, boxed, ref.ncross, int((ref.alive == 0).sum()))
     trk.close()
     return desc
 

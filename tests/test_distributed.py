@@ -288,6 +288,54 @@ def test_world2_gloo_partition_broadcast_gather():
     assert ncross > 100
 
 
+def _box_bcast_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from sitrack_amd import distributed as sd
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        Nj, Ni = 40, 52
+        rng = np.random.default_rng(11)
+        rec = rng.normal(size=3 * Nj * Ni).astype(np.float32)                 # the record (rank 0 holds it)
+        old = np.full(3 * Nj * Ni, -7.0, dtype=np.float32)                     # what the other ranks' slots held before
+        slot = torch.from_numpy(rec.copy() if rank == 0 else old.copy())
+        # every rank's own box; rank 2 has no live buoy (empty box)
+        mine = [(5, 20, 8, 24), (12, 31, 4, 16), (0, 0, 0, 0)][rank]
+        box = sd.union_box(mine, Nj, Ni)
+        ok = box == (5, 31, 4, 24)
+        buf = torch.empty(3 * (box[1] - box[0]) * (box[3] - box[2]), dtype=torch.float32)
+        moved = sd.broadcast_box(slot, Nj, Ni, box, buf, src=0)
+        ok = ok and moved == 3 * 26 * 20 * 4
+        want = (rec if rank == 0 else old).reshape(3, Nj, Ni).copy()
+        want[:, box[0]:box[1], box[2]:box[3]] = rec.reshape(3, Nj, Ni)[:, box[0]:box[1], box[2]:box[3]]
+        ok = ok and np.array_equal(slot.numpy().reshape(3, Nj, Ni), want)
+        ok = ok and sd.union_box((0, 0, 0, 0), Nj, Ni) == (0, 0, 0, 0)          # nobody has a live buoy
+        t = torch.tensor([1 if ok else 0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            q.put("ok" if int(t[0]) == 1 else "wrong box or contents on some rank")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_box_broadcast_world3_gloo():
+    """round 4: one broadcast of the union of the ranks' boxes instead of the whole slab (bench.py's `box_broadcast` segment):
+    three ranks, one of them without a live buoy; the box arrives in every slot, everything else of the slots is untouched."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_box_bcast_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    status = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert status == "ok", status
+
+
 class _CpuLayer:
     """Stand-in for torch.cuda in RecordBroadcaster: the host is the device, work runs when it is queued.  Events carry the
     sequence number of their last record(), so the test can audit WHAT each wait fences (the protocol), while the slot contents
@@ -591,8 +639,9 @@ def test_bench_multi_gpu_code_path_with_one_rccl_rank():
     assert d["solo_same_shard"]["value"] > 0 and 0.5 < d["efficiency_vs_n1_same_shard"] < 1.5      # one rank: the two legs are the same run
     e = d["e2e_broadcast"]
     assert "error" not in e, e
-    for mode in ("broadcast", "scatter_allgather"):
-        assert e[mode]["ms_per_step"] > 0 and e[mode]["particle_steps_per_s"] > 0
+    for mode in ("broadcast", "scatter_allgather", "box_broadcast"):
+        assert e[mode]["ms_per_step"] > 0 and e[mode]["particle_steps_per_s"] > 0, e[mode]
+    assert 0.2 < e["box_broadcast"]["share_of_slab"] < 0.9
     assert e["slab_bytes"] == 3 * 512 * 512 * 4
 
 

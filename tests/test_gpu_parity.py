@@ -917,6 +917,32 @@ def test_partly_uploaded_slot_is_checked_against_the_buoys_band():
         trk.close()
 
 
+def test_restore_state_keeps_the_alive_means_kill_rec_minus_one_invariant():
+    """the re-sort rebuilds a live buoy's kill record as -1 (permute_state_kernel gathers it for dead buoys only), so
+    `sitrk_restore_state` must not plant another value on a live buoy: what sitrk_fetch answers may not change across a sort."""
+    grid = syn.make_grid(64, 64, dkm=4.0, warp=0.0)
+    _, yx = syn.make_buoys(grid, 3000, seed=3, frac=0.6)
+    trk = make_tracker(grid, grid["tmask"], 1)
+    try:
+        found, ji, _ = sit.FindContainingCell(yx, syn.nearest_t_plane(grid, yx), ctx=trk.ctx)
+        yx, ji = yx[found], ji[found]
+        n = len(yx)
+        trk.ctx.set_buoys(yx, ji, sort=False)
+        alive = np.ones(n, dtype=np.int8); alive[::5] = 0
+        kill_rec = np.full(n, -1, dtype=np.int32); kill_rec[::5] = 7
+        kill_rec[1::5] = 3                                # a caller's stale value on LIVE buoys: ignored, stored as -1
+        trk.ctx.restore_state(alive, kill_rec)
+        before = trk.ctx.fetch()
+        trk.ctx.sort_buoys()
+        after = trk.ctx.fetch()
+        for k in ("yx", "jiT", "alive", "kill_rec"):
+            assert np.array_equal(before[k], after[k]), k
+        assert np.array_equal(after["alive"], alive)
+        assert np.all(after["kill_rec"][alive == 1] == -1) and np.all(after["kill_rec"][alive == 0] == 7)
+    finally:
+        trk.close()
+
+
 def test_run_many_steps_equals_stepping(ctx):
     grid = syn.make_grid(96, 96, dkm=4.0, warp=1.0)
     u, v, sic = syn.make_fields(grid, K=3, seed=3, umax=0.6, drift=0.2)
