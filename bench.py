@@ -397,8 +397,9 @@ def fresh_records_leg(ctx, K, fuse, s0, nsteps, sync):
         if pending:
             jmin, jmax, imin, imax, age = ctx.buoy_box_end()        # queued before the previous launch: does not wait for it
         box = ctx.box_of(jmin, jmax, imin, imax, age + m - 1)
-        ctx.buoy_box_begin()
-        pending = True
+        pending = k + m < nsteps                         # (the last launch needs no successor's box)
+        if pending:
+            ctx.buoy_box_begin()
         ctx.commit_records_box((s0 + k) % K, m, *box)
         ctx.run((s0 + k) % K, s0 + k, m)
         cells.append((box[1] - box[0]) * (box[3] - box[2]))

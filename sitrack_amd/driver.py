@@ -213,8 +213,23 @@ class _Clock:
         return self.now()
 
 
+def _tame_malloc():
+    """The command line's host memory is O(nP) by design (the series is streamed); glibc would still keep hundreds of MB of
+    freed record-sized buffers in per-thread arenas (the output is deflated on up to 16 threads, each allocating and freeing
+    4-MB pieces): allocations of 1 MB and more go straight to mmap (returned to the system when freed, no dynamic threshold)
+    and the arenas are capped.  Best effort, Linux / glibc only; the library itself never touches the allocator."""
+    try:
+        import ctypes
+        libc = ctypes.CDLL(None)
+        libc.mallopt(-3, 1 << 20)        # M_MMAP_THRESHOLD
+        libc.mallopt(-8, 4)              # M_ARENA_MAX
+    except Exception:                    # noqa: BLE001
+        pass
+
+
 def main(argv=None):
     a = parse_args(argv)
+    _tame_malloc()
     clk = _Clock()
     cf_uv, cf_mm, fNCseed, jrecSeed, cdate_stop, CONF = a.fsi3, a.fmmm, a.fsdg, a.krec, a.dend, a.ncnf
     lUse2DTime = not a.fxdt

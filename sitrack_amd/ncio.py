@@ -481,7 +481,7 @@ class CloudBuoysStream:
     written as raw chunks, flushed every `flush_bytes`; netCDF4 or the NetCDF-3 fall-back: one record slice per variable)."""
 
     def __init__(self, cf_out, ptime, pIDs, with_mask=True, tunits=tunits_default, fillVal=FillValue, corigin=None,
-                 cauthor='si3_part_tracker.py', flush_bytes=256 << 20):
+                 cauthor='si3_part_tracker.py', flush_bytes=None):
         from . import h5lite
         self.path, self.Nt, self.Nb = cf_out, len(ptime), len(pIDs)
         self.with_mask, self.nput = with_mask, 0
@@ -491,7 +491,9 @@ class CloudBuoysStream:
         self.w = self.f = None
         if _nc4 is None and h5lite.writer_available():
             self.w = _nc4_hdf5_create(cf_out, self.Nt, pIDs, with_mask, False, tunits, fillVal, corigin, about, author)
-            self.flush_bytes, self.queued = int(flush_bytes), 0
+            # rows wait (as arrays + deflated blobs) until this many bytes are queued: the writer's share of the peak memory
+            self.flush_bytes = int(flush_bytes if flush_bytes is not None else os.environ.get('SITRK_NC_FLUSH_BYTES', str(96 << 20)))
+            self.queued = 0
             self.w.write('time', np.asarray(ptime).astype('i4'))
             return
         if _nc4 is not None:

@@ -532,10 +532,11 @@ def test_cli_F_streams_the_series_in_bounded_memory_and_out_stride(tmp_path, mon
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     Nrec = 200
     c = make_case(str(tmp_path), nrec=Nrec, nP=1_150_000)
-    launcher = ("import json, resource, sys; sys.path.insert(0, %r); from sitrack_amd import driver as drv; "
+    launcher = ("import json, sys; sys.path.insert(0, %r); from sitrack_amd import driver as drv; "
                 "out = drv.main(sys.argv[1:]); "
                 "print('RESULT ' + json.dumps({'files': out['files'], 'nP': int(out['nP']), 'launches': out['launches'], "
-                "'maxrss_kb': resource.getrusage(resource.RUSAGE_SELF).ru_maxrss}))" % root)
+                "'maxrss_kb': int([l.split()[1] for l in open('/proc/self/status') if l.startswith('VmHWM')][0])}))" % root)
+    # (VmHWM, not ru_maxrss: the latter survives fork + exec, i.e. it starts at whatever the pytest process had resident)
     res = {}
     for tag, extra in (("full", []), ("stride", ["--out-stride", "8"])):
         r = subprocess.run([sys.executable, "-c", launcher, "-i", c["si3"], "-m", c["mm"], "-s", c["seed"], "-N", "TEST4", "-F"] + extra,
