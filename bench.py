@@ -200,6 +200,9 @@ def parse():
     ap.add_argument("--tune", default="", help="library tuning knobs for A/B runs, e.g. patch_kb=0,sort_tile=2080 (never change results)")
     ap.add_argument("--no-c2", action="store_true", help="skip the C2 (512x512, 1e5 buoys, 1000 steps) sub-measurement")
     ap.add_argument("--no-fresh", action="store_true", help="skip the fresh-records leg (every record committed once, inside the clock)")
+    ap.add_argument("--fresh-overlap", action="store_true",
+                    help="fresh-records leg with the commits on the library's ingest stream, next to the launch that steps with the other "
+                         "half of the slot ring (measured slower than committing on the compute stream: not the default)")
     ap.add_argument("--no-c4-shard", action="store_true", help="N = 1: skip the C4 per-rank shard sub-measurement")
     ap.add_argument("--no-e2e-upload", action="store_true", help="N = 1: skip the short end-to-end upload segment")
     ap.add_argument("--no-e2e-broadcast", action="store_true",
@@ -376,34 +379,51 @@ def c2_subrun(sit, syn, dev, a, steps=1000, warmup=64):
         ctx.close()
 
 
-def fresh_records_leg(ctx, K, fuse, s0, nsteps, sync):
+def fresh_records_leg(ctx, K, fuse, s0, nsteps, sync, overlap=False):
     """The timed run once more with NOTHING amortised over the record cycling: every record stepped with is committed afresh
     right before the launch that uses it (sitrk_commit_records_box: its Survive bytes re-derived from its siconc, over the box the
     buoys can touch, one Survive launch per fused launch), inside the clock.  What a run over distinct records pays per record
     when the slabs arrive in device memory (an RCCL broadcast, a device-side producer); an upload over PCIe hides it (e2e_upload).
     The box comes from sitrk_buoy_box_begin/_end: the evaluation is queued one launch ahead and collected while the next launch
-    runs, so the stream never drains; a box is therefore up to 2 x fuse - 1 records old and that many cells wider all around."""
+    runs, so the stream never drains; a box is therefore up to 2 x fuse - 1 records old and that many cells wider all around.
+    overlap=True (bench.py --fresh-overlap; measured, NOT the default: profiles/r04r_*): launches of half the slot ring, the other
+    half committed on the library's ingest stream next to the running launch (sitrk_commit_records_box_async) -- the fused loop
+    needs its seven waves per SIMD, a co-running memory-bound kernel costs it more than the 11 us per record it hides."""
+    m = max(1, min(fuse, K // 2 if K > 1 else 1)) if overlap else fuse
+    ctx.set_tuning(fuse=m)
     sync()
     ctx.launch_stats(reset=True)
-    jmin, jmax, imin, imax = ctx.buoy_box()
-    age = 0
+    ev, ev_age = ctx.buoy_box(), 0                       # the evaluation in hand and the records stepped since its begin
     pending = False
     cells = []
     ctx.timer_start()
     t0 = time.perf_counter()
+
+    def commit(k, cnt, age):
+        box = ctx.box_of(*ev, age + cnt - 1)
+        ctx.commit_records_box((s0 + k) % K, cnt, *box, on_ingest_stream=overlap)
+        cells.append((box[1] - box[0]) * (box[3] - box[2]))
+
+    if overlap:
+        commit(0, min(m, nsteps), ev_age)
     k = 0
     while k < nsteps:
-        m = min(fuse, nsteps - k)
+        mk = min(m, nsteps - k)
         if pending:
-            jmin, jmax, imin, imax, age = ctx.buoy_box_end()        # queued before the previous launch: does not wait for it
-        box = ctx.box_of(jmin, jmax, imin, imax, age + m - 1)
-        pending = k + m < nsteps                         # (the last launch needs no successor's box)
-        if pending:
+            r = ctx.buoy_box_end()                       # queued before the previous launch: does not wait for it
+            ev, ev_age, pending = r[:4], r[4], False
+        k2 = k + mk
+        m2 = min(m, nsteps - k2)
+        if m2 > 0 and (not overlap or k2 + m2 < nsteps): # (the last launches need no fresher box)
             ctx.buoy_box_begin()
-        ctx.commit_records_box((s0 + k) % K, m, *box)
-        ctx.run((s0 + k) % K, s0 + k, m)
-        cells.append((box[1] - box[0]) * (box[3] - box[2]))
-        k += m
+            pending = True
+        if not overlap:
+            commit(k, mk, ev_age)
+        ctx.run((s0 + k) % K, s0 + k, mk)
+        ev_age += mk
+        if overlap and m2 > 0:                           # the other half of the ring, prepared while the launch above runs
+            commit(k2, m2, ev_age)
+        k = k2
     ms = ctx.timer_stop()
     sync()
     dt = time.perf_counter() - t0
@@ -411,19 +431,20 @@ def fresh_records_leg(ctx, K, fuse, s0, nsteps, sync):
         ctx.buoy_box_end()
     st = ctx.launch_stats(reset=True)
     # the Survive pass alone, same box, same batch size (its share of the time above)
-    box = ctx.box(fuse - 1)
-    m = min(fuse, K)
-    ctx.commit_records_box(0, m, *box)
+    mm = min(m, K)
+    box = ctx.box(mm - 1)
+    ctx.commit_records_box(0, mm, *box)
     ctx.sync()
     ctx.timer_start()
     for _ in range(5):
-        ctx.commit_records_box(0, m, *box)
+        ctx.commit_records_box(0, mm, *box)
     sv_ms = ctx.timer_stop()
     for slot in range(K):
         ctx.commit_record(slot)                          # the resident legs that follow see whole records again
     ctx.sync()
-    return {"dt": dt, "event_ms": ms, "stats": st, "box_cells_mean": float(np.mean(cells)), "survive_us_per_record": 1e3 * sv_ms / (5 * m),
-            "box": list(box)}
+    ctx.set_tuning(fuse=fuse)
+    return {"dt": dt, "event_ms": ms, "stats": st, "box_cells_mean": float(np.mean(cells)), "survive_us_per_record": 1e3 * sv_ms / (5 * mm),
+            "box": list(box), "records_per_launch": m, "overlap": overlap}
 
 
 def c4_shard_subrun(a, syn, ctx, w, K, fuse, s0, barrier):
@@ -822,7 +843,7 @@ def main():
         if fuse > 1 and not a.only_fused and not a.no_fresh:
             # right behind the headline leg (the box the buoys can touch grows as the cloud rotates: same state, same launches)
             _phase("fresh-records leg")
-            fresh = fresh_records_leg(ctx, K, fuse, nrun, a.steps, barrier)
+            fresh = fresh_records_leg(ctx, K, fuse, nrun, a.steps, barrier, overlap=a.fresh_overlap)
             nrun += a.steps
         if fuse > 1 and not a.only_fused:
             # for reference: the same K steps with one launch per record (the HBM-bound form of the kernel)
@@ -1163,6 +1184,7 @@ def main():
                 "event_ms_per_step": fresh["event_ms"] / a.steps, "survive_us_per_record": fresh["survive_us_per_record"],
                 "survive_box_cells": fresh["box_cells_mean"], "survive_box_share_of_grid": fresh["box_cells_mean"] / float(Nj * Ni),
                 "launches": fs["fused_launches"], "records_advanced": fs["fused_records"] + fs["step_launches"],
+                "records_per_launch": fresh["records_per_launch"], "commits_overlap_the_stepping": fresh["overlap"],
                 "note": "same steps, same launches; before each launch its records are committed afresh (sitrk_commit_records_box: "
                         "Survive re-derived from siconc over the box the buoys can touch, ONE Survive launch per fused launch; the box "
                         "from sitrk_buoy_box_begin/_end queued one launch ahead), all inside the timed region"}

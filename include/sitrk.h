@@ -23,10 +23,11 @@
  *     own pinned staging before the call comes back (a C caller may free or
  *     overwrite them at once), outputs are complete on return.  Device pointers
  *     passed to *_dev entry points must stay valid until the next sitrk_sync()/fetch.
- *   - threading: one compute stream and one copy stream per context.  Record
- *     uploads (sitrk_push_record*, sitrk_stage_submit) run on the copy stream
- *     out of double-buffered pinned staging and are ordered against the kernels
- *     by events only, so the next records travel while the current ones are
+ *   - threading: one compute stream and one copy stream per context (+ an ingest
+ *     stream for the opt-in asynchronous Survive derivation).  Record uploads
+ *     (sitrk_push_record*, sitrk_stage_submit*) run on the copy stream out of
+ *     double-buffered pinned staging and are ordered against the kernels by
+ *     events only, so the next records travel while the current ones are
  *     stepped with (SURVEY 8b "async, double-buffered").
  *   - there is NO CPU fallback: without a usable HIP device sitrk_create()
  *     fails with SITRK_EHIP.
@@ -90,6 +91,8 @@ int sitrk_set_params(sitrk_t *h, double rdt, int uv_strategy, double rmin_conc);
  * order of the cell sort, tile-major tiles of tile_j x tile_i cells; "locate_bruteforce" (0/1):
  * SeedInit scans the whole grid per seed like the reference instead of the bounding-sphere search; "survive_tile" (0/1): derive a
  * record's Survive bytes with the LDS-tile kernel even where the register-rolling one applies (meshes with Ni % 4 == 0);
+ * "async_survive" (0/1, default 0): an uploaded record's Survive bytes are derived on the compute stream (0) or on the library's
+ * ingest stream, next to the stepping of the resident records (1: measured slower under the fused loop, kept as a knob);
  * "fill_threads" (1..16, default 8): host threads that copy a pushed record of 8 MB or more into the pinned staging;
  * "patch_kb" (0..63, default 16) / "patch_margin" (0..64, default 8): KB of LDS per workgroup that the fused kernel may fill with
  * the F-points of the cells around its buoys (0 = none: every geometry read goes to global memory), and the widest margin of
@@ -175,6 +178,11 @@ int sitrk_commit_record_box(sitrk_t *h, int slot, int j0, int j1, int i0, int i1
 /* the same box of the nrec records in slots (slot0 + k) % nslots, k < nrec (the slots a sitrk_run of nrec records from slot0
  * steps with), derived by ONE launch: a box of a record is ~10 us of memory traffic, of the order of a dependent dispatch */
 int sitrk_commit_records_box(sitrk_t *h, int slot0, int nrec, int j0, int j1, int i0, int i1);
+/* the same on the library's INGEST stream instead of the compute stream: the derivation runs next to the launches that step with
+ * OTHER slots -- behind the last launch that read these slots' bytes, in front of the first one that will (knob "async_survive": the
+ * same for uploaded records).  For slabs that are COMPLETE in device memory when the call is made: nothing may still be writing them.
+ * Measured (bench.py --fresh-overlap): slower than the plain call under the fused loop -- an option, not the default path. */
+int sitrk_commit_records_box_async(sitrk_t *h, int slot0, int nrec, int j0, int j1, int i0, int i1);
 
 /* ---- buoys ---------------------------------------------------------------
  * State of si3_part_tracker.py:324-330 reduced to what the loop reads:

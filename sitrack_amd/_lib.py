@@ -52,6 +52,7 @@ _SIGNATURES = {
     "sitrk_stage_submit_box": (_int, [_vp, _int, _int, _int, _int, _int]),
     "sitrk_commit_record_box": (_int, [_vp, _int, _int, _int, _int, _int]),
     "sitrk_commit_records_box": (_int, [_vp, _int, _int, _int, _int, _int, _int]),
+    "sitrk_commit_records_box_async": (_int, [_vp, _int, _int, _int, _int, _int, _int]),
     "sitrk_record_ptr": (_vp, [_vp, _int]),
     "sitrk_commit_record": (_int, [_vp, _int]),
     "sitrk_set_buoys": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
@@ -351,9 +352,11 @@ class Context:
     def commit_record_box(self, slot, j0, j1, i0, i1):
         self._chk(self._L.sitrk_commit_record_box(self._h, int(slot), int(j0), int(j1), int(i0), int(i1)))
 
-    def commit_records_box(self, slot0, nrec, j0, j1, i0, i1):
-        """commit_record_box for the nrec slots (slot0 + k) % nslots in one launch"""
-        self._chk(self._L.sitrk_commit_records_box(self._h, int(slot0), int(nrec), int(j0), int(j1), int(i0), int(i1)))
+    def commit_records_box(self, slot0, nrec, j0, j1, i0, i1, on_ingest_stream=False):
+        """commit_record_box for the nrec slots (slot0 + k) % nslots in one launch; on_ingest_stream: next to the stepping of other
+        slots (sitrk_commit_records_box_async: the slabs must be complete in device memory)"""
+        fn = self._L.sitrk_commit_records_box_async if on_ingest_stream else self._L.sitrk_commit_records_box
+        self._chk(fn(self._h, int(slot0), int(nrec), int(j0), int(j1), int(i0), int(i1)))
 
     def push_record_rows(self, slot, j0, j1, u_rows, v_rows, sic_rows):
         shp = (j1 - j0, self.Ni)

@@ -109,6 +109,7 @@ SITRK_API int sitrk_create(sitrk_t **out, int device)
     for (int k = 0; k < 4096; k++) c->slot_used_seq[k] = -1;
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->sv_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     for (int b = 0; b < sitrk_ctx::kStage && e == hipSuccess; b++) e = hipEventCreateWithFlags(&c->stage_done[b], hipEventDisableTiming);
@@ -131,6 +132,7 @@ SITRK_API int sitrk_destroy(sitrk_t *h)
     if (!h) return SITRK_OK;
     (void)hipSetDevice(h->device);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+    if (h->sv_stream) (void)hipStreamSynchronize(h->sv_stream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_buoys(h);
     free_records(h);
@@ -143,6 +145,8 @@ SITRK_API int sitrk_destroy(sitrk_t *h)
     for (int b = 0; b < sitrk_ctx::kStage; b++) if (h->stage_done[b]) (void)hipEventDestroy(h->stage_done[b]);
     for (int k = 0; k < sitrk_ctx::kLaunchRing; k++) if (h->launch_ev[k]) (void)hipEventDestroy(h->launch_ev[k]);
     for (int k = 0; k < 4096; k++) if (h->slot_ready[k]) (void)hipEventDestroy(h->slot_ready[k]);
+    for (int k = 0; k < 4096; k++) if (h->slot_sv[k]) (void)hipEventDestroy(h->slot_sv[k]);
+    if (h->sv_stream) (void)hipStreamDestroy(h->sv_stream);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -153,6 +157,7 @@ SITRK_API int sitrk_sync(sitrk_t *h)
 {
     NEED(h, "null handle");
     HIPCHK(hipStreamSynchronize(h->copy_stream));
+    HIPCHK(hipStreamSynchronize(h->sv_stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return SITRK_OK;
 }
@@ -177,6 +182,7 @@ SITRK_API int sitrk_set_grid(sitrk_t *h, int Nj, int Ni, const double *Yf, const
         return fail(h, SITRK_EINVAL, "sitrk_set_grid: grid %dx%d has more than 2^29 cells", Nj, Ni);
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->copy_stream));
+    HIPCHK(hipStreamSynchronize(h->sv_stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     dev_free(h->geo); dev_free(h->geoF); dev_free(h->orient); dev_free(h->tmask);
     h->geo = nullptr; h->geoF = nullptr; h->orient = nullptr; h->tmask = nullptr;
@@ -258,6 +264,10 @@ SITRK_API int sitrk_set_tuning(sitrk_t *h, const char *knob, int value)
         h->xcd_group = value;
         return SITRK_OK;
     }
+    else if (!strcmp(knob, "async_survive")) {       // uploads derive their Survive bytes on the ingest stream (1) or on the compute stream (0)
+        h->async_survive = value != 0;
+        return SITRK_OK;
+    }
     else if (!strcmp(knob, "fill_threads")) {        // host threads that copy a pushed record into the pinned staging
         if (value < 1 || value > 16) return fail(h, SITRK_EINVAL, "sitrk_set_tuning: fill_threads must be 1..16");
         h->fill_threads = value;
@@ -292,6 +302,7 @@ static void free_records(sitrk_ctx *h)
     }
     h->stage_bytes = 0; h->stage_rows = -1; h->stage_cols = 0; h->stage_next = 0;
     memset(h->slot_pending, 0, sizeof(h->slot_pending));
+    memset(h->slot_sv_pending, 0, sizeof(h->slot_sv_pending));
     memset(h->slot_dirty, 1, sizeof(h->slot_dirty));
     for (int k = 0; k < 4096; k++) {
         h->slot_used_seq[k] = -1;
@@ -308,6 +319,7 @@ SITRK_API int sitrk_alloc_records(sitrk_t *h, int nslots, int dtype)
     NEED(dtype == SITRK_F32 || dtype == SITRK_F64, "sitrk_alloc_records: dtype must be SITRK_F32 or SITRK_F64");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->copy_stream));
+    HIPCHK(hipStreamSynchronize(h->sv_stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     free_records(h);
     const size_t n = (size_t)h->Nj * h->Ni;
@@ -344,6 +356,16 @@ static int slot_wait_upload(sitrk_ctx *h, int slot)
     return SITRK_OK;
 }
 
+// ... and behind a Survive derivation of the slot still in flight on the ingest stream
+static int slot_wait_sv(sitrk_ctx *h, int slot)
+{
+    if (h->slot_sv_pending[slot]) {
+        HIPCHK(hipStreamWaitEvent(h->stream, h->slot_sv[slot], 0));
+        h->slot_sv_pending[slot] = 0;
+    }
+    return SITRK_OK;
+}
+
 // One event per launch (a ring of them): an upload into a slot waits for the last launch that read it, not for the
 // whole compute stream, so the next records travel while the current ones are stepped with.
 static int launch_mark(sitrk_ctx *h, const int *slots, int nslots_used)
@@ -358,8 +380,10 @@ static int launch_mark(sitrk_ctx *h, const int *slots, int nslots_used)
 // exactly that box, one pass, ONE launch: record k's siconc field is sic + slots[k] * sic_stride elements, its Survive arrays
 // kill / kill9 + slots[k] * kill_stride bytes (f64 or f32; a probe passes one record with strides 0)
 static int launch_survive(sitrk_ctx *h, bool f64, const void *sic, int8_t *kill, uint8_t *kill9, int j0, int j1, int i0, int i1,
-                          const int *slots = nullptr, int nb = 1, long long sic_stride = 0, long long kill_stride = 0)
+                          const int *slots = nullptr, int nb = 1, long long sic_stride = 0, long long kill_stride = 0,
+                          hipStream_t stream = nullptr)
 {
+    if (!stream) stream = h->stream;
     SvBox bx;
     bx.j_lo = j0; bx.j_hi = j1; bx.v_lo = j0; bx.v_hi = j1;
     bx.cv_lo = i0; bx.cv_hi = i1;
@@ -374,38 +398,64 @@ static int launch_survive(sitrk_ctx *h, bool f64, const void *sic, int8_t *kill,
         // (8 rows per wave instead of 16 for small boxes was measured: no gain alone, 15 % slower in a batch -- profiles/r04b_sv_box.jsonl)
         const dim3 g(gx, (unsigned)((j1 - j0 + 4 * kSvRowsR - 1) / (4 * kSvRowsR)), (unsigned)nb);
         if (f64)
-            hipLaunchKernelGGL((survive_kill9_rows_kernel<double>), g, dim3(256), 0, h->stream, h->Nj, h->Ni, bx, sb, h->tmask,
+            hipLaunchKernelGGL((survive_kill9_rows_kernel<double>), g, dim3(256), 0, stream, h->Nj, h->Ni, bx, sb, h->tmask,
                                (const double *)sic, h->rmin_conc, kill, kill9);
         else
-            hipLaunchKernelGGL((survive_kill9_rows_kernel<float>), g, dim3(256), 0, h->stream, h->Nj, h->Ni, bx, sb, h->tmask,
+            hipLaunchKernelGGL((survive_kill9_rows_kernel<float>), g, dim3(256), 0, stream, h->Nj, h->Ni, bx, sb, h->tmask,
                                (const float *)sic, h->rmin_conc, kill, kill9);
     } else {
         bx.c_hi = i1;
         const dim3 grid((unsigned)((bx.c_hi - bx.c_lo + kSvTC - 1) / kSvTC), (unsigned)((j1 - j0 + kSvTR - 1) / kSvTR), (unsigned)nb);
         if (f64)
-            hipLaunchKernelGGL((survive_kill9_kernel<double>), grid, dim3(kSvBlock), 0, h->stream, h->Nj, h->Ni, bx, sb, h->tmask,
+            hipLaunchKernelGGL((survive_kill9_kernel<double>), grid, dim3(kSvBlock), 0, stream, h->Nj, h->Ni, bx, sb, h->tmask,
                                (const double *)sic, h->rmin_conc, kill, kill9);
         else
-            hipLaunchKernelGGL((survive_kill9_kernel<float>), grid, dim3(kSvBlock), 0, h->stream, h->Nj, h->Ni, bx, sb, h->tmask,
+            hipLaunchKernelGGL((survive_kill9_kernel<float>), grid, dim3(kSvBlock), 0, stream, h->Nj, h->Ni, bx, sb, h->tmask,
                                (const float *)sic, h->rmin_conc, kill, kill9);
     }
     HIPCHK(hipGetLastError());
     return SITRK_OK;
 }
 
-// derive the Survive bytes of the box rows [j0,j1) x columns [i0,i1) of `nb` slots from their siconc there, in one launch
-// (queued on the compute stream behind the slots' uploads)
-static int derive_mask_box_batch(sitrk_ctx *h, const int *slots, int nb, int j0, int j1, int i0, int i1)
+// derive the Survive bytes of the box rows [j0,j1) x columns [i0,i1) of `nb` slots from their siconc there, in one launch.
+//   on_ingest = false: on the compute stream, behind the slots' uploads and behind whatever the caller queued there before (a slab
+//                      written in place through sitrk_record_ptr is ordered against the compute stream by its writer);
+//   on_ingest = true : on the ingest stream (sv_stream), next to the stepping of OTHER slots: behind the slots' uploads, behind the
+//                      last launch that read these slots' bytes, and in front of the first launch that will (slot_sv events).
+static int derive_mask_box_batch(sitrk_ctx *h, const int *slots, int nb, int j0, int j1, int i0, int i1, bool on_ingest = false)
 {
     const size_t n = (size_t)h->Nj * h->Ni, es = elem_size(h->dtype);
-    for (int k = 0; k < nb; k++) {
-        int rc = slot_wait_upload(h, slots[k]);
-        if (rc) return rc;
-    }
-    if (!(j0 >= j1 || i0 >= i1)) {                      // (a slot that holds nothing: check_band refuses to step with it)
+    const bool empty = (j0 >= j1 || i0 >= i1);           // (a slot that holds nothing: check_band refuses to step with it)
+    if (!on_ingest) {
+        for (int k = 0; k < nb; k++) {
+            int rc = slot_wait_upload(h, slots[k]);
+            if (rc) return rc;
+            rc = slot_wait_sv(h, slots[k]);             // an earlier derivation of the same slot writes the same bytes
+            if (rc) return rc;
+        }
+        if (!empty) {
+            int rc = launch_survive(h, h->dtype == SITRK_F64, (const char *)h->slabs + 2 * n * es, nullptr, h->kill9, j0, j1, i0, i1,
+                                    slots, nb, (long long)(h->slab_bytes / es), (long long)n);
+            if (rc) return rc;
+            rc = launch_mark(h, slots, nb);             // it reads the slots' siconc and writes their bytes: uploads and ingest-side
+            if (rc) return rc;                          // derivations of these slots stay behind it
+        }
+    } else if (!empty) {
+        for (int k = 0; k < nb; k++) {
+            const int slot = slots[k];
+            if (h->slot_pending[slot]) HIPCHK(hipStreamWaitEvent(h->sv_stream, h->slot_ready[slot], 0));     // (the compute stream waits for it too)
+            if (h->slot_used_seq[slot] >= 0)
+                HIPCHK(hipStreamWaitEvent(h->sv_stream, h->launch_ev[h->slot_used_seq[slot] % sitrk_ctx::kLaunchRing], 0));
+        }
         int rc = launch_survive(h, h->dtype == SITRK_F64, (const char *)h->slabs + 2 * n * es, nullptr, h->kill9, j0, j1, i0, i1,
-                                slots, nb, (long long)(h->slab_bytes / es), (long long)n);
+                                slots, nb, (long long)(h->slab_bytes / es), (long long)n, h->sv_stream);
         if (rc) return rc;
+        for (int k = 0; k < nb; k++) {
+            const int slot = slots[k];
+            if (!h->slot_sv[slot]) HIPCHK(hipEventCreateWithFlags(&h->slot_sv[slot], hipEventDisableTiming));
+            HIPCHK(hipEventRecord(h->slot_sv[slot], h->sv_stream));
+            h->slot_sv_pending[slot] = 1;
+        }
     }
     for (int k = 0; k < nb; k++) h->slot_dirty[slots[k]] = 0;
     return SITRK_OK;
@@ -486,8 +536,10 @@ static int stage_submit_box(sitrk_ctx *h, int slot, int j0, int j1, int i0, int 
     const size_t nb = (size_t)nr * nc * es;
     char *d = slab_of(h, slot);
     const char *src = (const char *)h->stage[b];
-    // the copy may not overtake kernels that still read the slot; nothing else on the compute stream holds it back
+    // the copy may not overtake kernels that still read the slot -- the last launch that stepped with it, the last Survive derivation
+    // that read its siconc on the ingest stream; nothing else on the compute stream holds it back
     if (h->slot_used_seq[slot] >= 0) HIPCHK(hipStreamWaitEvent(h->copy_stream, h->launch_ev[h->slot_used_seq[slot] % sitrk_ctx::kLaunchRing], 0));
+    if (h->slot_sv[slot]) HIPCHK(hipStreamWaitEvent(h->copy_stream, h->slot_sv[slot], 0));
     for (int f = 0; f < 3; f++) {
         char *df = d + (size_t)f * n * es + ((size_t)j0 * h->Ni + i0) * es;
         if (nc == h->Ni) HIPCHK(hipMemcpyAsync(df, src + (size_t)f * nb, nb, hipMemcpyHostToDevice, h->copy_stream));
@@ -501,10 +553,9 @@ static int stage_submit_box(sitrk_ctx *h, int slot, int j0, int j1, int i0, int 
     h->stage_rows = -1;
     h->stage_next = (b + 1) % sitrk_ctx::kStage;
     slot_holds(h, slot, j0, j1, i0, i1);
-    // the Survive bytes this box determines, on the compute stream behind the upload
-    int rc = derive_mask_box(h, slot, j0, j1, i0, i1);
-    if (rc) return rc;
-    return launch_mark(h, &slot, 1);    // that kernel reads the slot's siconc: a later upload into the slot stays behind it
+    // the Survive bytes this box determines, behind the upload: on the ingest stream (next to the stepping of the resident records;
+    // the first launch that reads the slot waits for it) or, knob async_survive = 0, on the compute stream as in rounds 1-3
+    return derive_mask_box_batch(h, &slot, 1, j0, j1, i0, i1, h->async_survive != 0);
 }
 
 SITRK_API int sitrk_stage_submit(sitrk_t *h, int slot, int j0, int j1)
@@ -737,7 +788,19 @@ SITRK_API int sitrk_commit_record_box(sitrk_t *h, int slot, int j0, int j1, int 
     return derive_mask_box(h, slot, j0, j1, i0, i1);
 }
 
+static int commit_records_box(sitrk_ctx *h, int slot0, int nrec, int j0, int j1, int i0, int i1, bool on_ingest);
+
 SITRK_API int sitrk_commit_records_box(sitrk_t *h, int slot0, int nrec, int j0, int j1, int i0, int i1)
+{
+    return commit_records_box(h, slot0, nrec, j0, j1, i0, i1, false);
+}
+
+SITRK_API int sitrk_commit_records_box_async(sitrk_t *h, int slot0, int nrec, int j0, int j1, int i0, int i1)
+{
+    return commit_records_box(h, slot0, nrec, j0, j1, i0, i1, true);
+}
+
+static int commit_records_box(sitrk_ctx *h, int slot0, int nrec, int j0, int j1, int i0, int i1, bool on_ingest)
 {
     NEED(h, "null handle");
     NEED(h->slabs, "sitrk_commit_records_box: call sitrk_alloc_records first");
@@ -755,7 +818,7 @@ SITRK_API int sitrk_commit_records_box(sitrk_t *h, int slot0, int nrec, int j0, 
             else slot_holds(h, slots[q], j0, j1, i0, i1);
         }
         if (empty) continue;
-        int rc = derive_mask_box_batch(h, slots, nb, j0, j1, i0, i1);
+        int rc = derive_mask_box_batch(h, slots, nb, j0, j1, i0, i1, on_ingest);
         if (rc) return rc;
     }
     return SITRK_OK;
@@ -770,6 +833,8 @@ SITRK_API int sitrk_push_record_dev(sitrk_t *h, int slot, const void *slab_dev)
     HIPCHK(hipSetDevice(h->device));
     void *d = slab_of(h, slot);
     int rc = slot_wait_upload(h, slot);
+    if (rc) return rc;
+    rc = slot_wait_sv(h, slot);                         // (a derivation still reading the slot's siconc on the ingest stream)
     if (rc) return rc;
     if (d != slab_dev) HIPCHK(hipMemcpyAsync(d, slab_dev, h->slab_bytes, hipMemcpyDeviceToDevice, h->stream));
     slot_holds(h, slot, 0, h->Nj, 0, h->Ni);
@@ -999,6 +1064,8 @@ SITRK_API int sitrk_step(sitrk_t *h, int slot, int jrec)
     }
     rc = slot_wait_upload(h, slot);
     if (rc) return rc;
+    rc = slot_wait_sv(h, slot);
+    if (rc) return rc;
     const size_t n = (size_t)h->Nj * h->Ni, es = elem_size(h->dtype);
     const char *slab = slab_of(h, slot);
     BuoyState &s = h->st[h->cur];
@@ -1116,6 +1183,8 @@ SITRK_API int sitrk_run(sitrk_t *h, int slot0, int jrec0, int nsteps)
                 if (rc) return rc;
             }
             rc = slot_wait_upload(h, slot);
+            if (rc) return rc;
+            rc = slot_wait_sv(h, slot);
             if (rc) return rc;
             const char *slab = slab_of(h, slot);
             ra.u[r] = slab; ra.v[r] = slab + n * es; ra.kill9[r] = h->kill9 + (size_t)slot * n;

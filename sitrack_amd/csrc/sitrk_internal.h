@@ -31,6 +31,9 @@ struct sitrk_ctx {
     hipStream_t own_stream = nullptr;   // created by the library
     hipStream_t stream = nullptr;       // compute stream in use (own or adopted)
     hipStream_t copy_stream = nullptr;  // host -> device record uploads (overlap with stepping)
+    hipStream_t sv_stream = nullptr;    // Survive derivation of records that just arrived (round 4): ingest work -- the DMA on copy_stream,
+                                        // then the record's Survive bytes here -- runs NEXT TO the stepping of the resident records;
+                                        // the compute stream waits for a slot's event right before the first launch that reads the slot
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     // record ingest: library-owned pinned staging, double-buffered (sitrk_stage_acquire / sitrk_stage_submit).
@@ -78,6 +81,13 @@ struct sitrk_ctx {
     // into it waits for that launch's event in the ring below, not for the whole compute stream)
     unsigned char slot_pending[4096] = {0};
     hipEvent_t slot_ready[4096] = {nullptr};
+    // ... and a Survive derivation in flight on sv_stream: slot_sv[k] is recorded behind it (created on first use); the compute stream
+    // waits for it before it reads the slot's bytes (slot_sv_pending), an upload into the slot before it overwrites the siconc it reads
+    hipEvent_t slot_sv[4096] = {nullptr};
+    unsigned char slot_sv_pending[4096] = {0};
+    int async_survive = 0;              // knob: uploads derive their Survive bytes on sv_stream (1) or on the compute stream (0, default:
+                                        // next to the fused loop, which needs its seven waves per SIMD, the co-running kernel costs more
+                                        // than it hides -- profiles/r04r_*; behind a PCIe upload there is nothing to hide)
     long long slot_used_seq[4096];
     static constexpr int kLaunchRing = 64;
     hipEvent_t launch_ev[kLaunchRing] = {nullptr};

@@ -688,7 +688,7 @@ def test_row_band_ingest_equals_full_ingest(fdt):
 
 @pytest.mark.parametrize("fdt", [np.float32, np.float64])
 @pytest.mark.parametrize("Ni,tile", [(160, 0), (160, 1), (158, 0)])
-@pytest.mark.parametrize("mode", ["step", "run", "commit", "commit_run"])
+@pytest.mark.parametrize("mode", ["step", "run", "commit", "commit_run", "commit_run_async"])
 def test_box_ingest_equals_full_ingest(fdt, Ni, tile, mode):
     """Round 4: only the BOX rows [jmin-2, jmax+3) x columns [imin-2, imax+3) of a record is uploaded (three strided DMAs out of
     the pinned staging) and only its Survive bytes are derived; everything outside -- above, below, LEFT and RIGHT -- is poisoned
@@ -721,7 +721,7 @@ def test_box_ingest_equals_full_ingest(fdt, Ni, tile, mode):
                 return
             j0, j1, i0, i1 = ctx.box(age)
             boxes.append((j0, j1, i0, i1))
-            if mode in ("commit", "commit_run"):
+            if mode in ("commit", "commit_run", "commit_run_async"):
                 # the whole slab is written in device memory, poisoned outside the box; only the box is committed
                 import torch
                 from sitrack_amd import distributed as sd
@@ -735,12 +735,13 @@ def test_box_ingest_equals_full_ingest(fdt, Ni, tile, mode):
                     ctx.commit_record_box(slot, j0, j1, i0, i1)
                 elif slot == nfuse - 1:                             # the launch's records in ONE Survive launch
                     assert len(set(boxes[-nfuse:])) == 1
-                    ctx.commit_records_box(0, nfuse, j0, j1, i0, i1)
+                    # (_async: on the library's ingest stream, behind the launch that last read these slots' bytes)
+                    ctx.commit_records_box(0, nfuse, j0, j1, i0, i1, on_ingest_stream=(mode == "commit_run_async"))
             else:
                 ctx.push_record(slot, *poison)
                 ctx.push_record_box(slot, j0, j1, i0, i1, u[k][j0:j1, i0:i1], v[k][j0:j1, i0:i1], sic[k][j0:j1, i0:i1])
 
-        if mode in ("run", "commit_run"):
+        if mode in ("run", "commit_run", "commit_run_async"):
             for b in range(Nt // nfuse):
                 for r in range(nfuse):
                     deliver(r, (b * nfuse + r) % K, nfuse - 1)      # record r of a launch is stepped r records after the evaluation
@@ -757,7 +758,7 @@ def test_box_ingest_equals_full_ingest(fdt, Ni, tile, mode):
             alive = res[ingest]["iAlive"] == 1
             cells = res[ingest]["vJIt"][alive]
             assert (jmin, jmax, imin, imax) == (cells[:, 0].min(), cells[:, 0].max(), cells[:, 1].min(), cells[:, 1].max())
-            assert ctx.launch_stats()["fused_launches"] == (Nt // nfuse if mode in ("run", "commit_run") else 0)
+            assert ctx.launch_stats()["fused_launches"] == (Nt // nfuse if mode.endswith(("run", "run_async")) else 0)
         trk.close()
     for key in ("yx", "vJIt", "iAlive", "kill_rec"):
         assert np.array_equal(res["box"][key], res["full"][key]), key
@@ -799,7 +800,8 @@ def test_survive_bytes_of_a_box_equal_those_of_the_whole_record(ctx):
             assert np.array_equal(out[tile]["iAlive"], ref.alive) and np.array_equal(out[tile]["vJIt"], ref.jiT), (j0, j1, i0, i1, tile)
 
 
-def test_async_ingest_ring_and_staging():
+@pytest.mark.parametrize("async_survive", [0, 1])
+def test_async_ingest_ring_and_staging(async_survive):
     """Library-owned ingest (include/sitrk.h: pinned staging, copy stream, events): records are pushed from TEMPORARY host
     arrays that are scribbled over right after the call, pushed two batches ahead of the launches that use them, read
     straight into the pinned staging, and a slot is re-uploaded while the launch that used it may still be running --
@@ -816,6 +818,7 @@ def test_async_ingest_ring_and_staging():
         trk.set_buoys(yx, ji)
         ref = orc.Tracker(grid, yx, ji, nthreads=4)
         ctx = trk.ctx
+        ctx.set_tuning(async_survive=async_survive)         # 1: the uploads' Survive bytes are derived on the ingest stream (round 4 option)
         ref_done[0] = 0
 
         def upload(s):
@@ -975,7 +978,9 @@ def test_tuning_knobs_do_not_change_results():
                   {"sort_tile": 5 * 256 + 7, "nt_state": 1, "xcd_remap": 1},
                   # the fused kernel's LDS patch: none, tiny (most buoys leave it: global fallback), large; XCD grouping; one-record launches
                   {"patch_kb": 0}, {"patch_kb": 1, "patch_margin": 0}, {"patch_kb": 60, "patch_margin": 40}, {"xcd_group": 0},
-                  {"xcd_group": 5, "patch_kb": 3}, {"fuse": 1}, {"fuse": 2, "patch_kb": 2}, {"survive_tile": 1}):
+                  {"xcd_group": 5, "patch_kb": 3}, {"fuse": 1}, {"fuse": 2, "patch_kb": 2}, {"survive_tile": 1},
+                  # round 4: where an uploaded record's Survive bytes are derived (ingest stream / compute stream), host fill threads
+                  {"async_survive": 1}, {"async_survive": 1, "survive_tile": 1, "fill_threads": 1}, {"fill_threads": 16}):
         trk = make_tracker(grid, grid["tmask"], 3)
         found, ji, _ = sit.FindContainingCell(yx, syn.nearest_t_plane(grid, yx), ctx=trk.ctx)
         trk.ctx.set_tuning(**knobs)
