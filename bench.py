@@ -1049,6 +1049,8 @@ def main():
         except Exception:                                    # noqa: BLE001
             prof = {}
         prof_key = "c3" if a.config == "c4" else a.config    # C4's per-rank shard runs the C3 kernels on the C3 grid
+        if a.warp and (prof_key + "warp_fused") in prof:     # a counter profile of the curvilinear variant, when there is one
+            prof_key += "warp"
         prof_step, prof_fused = prof.get(prof_key, {}), prof.get(prof_key + "_fused", {})
         nwaves = (nP + 63) // 64
 

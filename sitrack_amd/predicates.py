@@ -130,22 +130,51 @@ def Haversine(plat, plon, xlat, xlon, ctx=None):
     return _default(ctx).eval_haversine(float(plat), float(plon), xlat, np.asarray(xlon, dtype=np.float64)).reshape(xlat.shape)
 
 
+def nearest_point_with_previous(haversine, pntGcoor, lat, lon, rd_found_km, res, ji_prv, np_box_r, max_itr):
+    """`NearestPoint` with a previous position (reference locate.py:241-271): the first pass searches the box of `np_box_r` points
+    around `ji_prv`, every later pass the whole domain; the acceptance radius starts at 0.5 * resolkm[jy, jx] -- indexed, like the
+    reference, by the minimum's position INSIDE THE BOX -- or at `rd_found_km`, and grows by 20 % per failed pass after the first.
+    `haversine(plat, plon, xlat, xlon)` evaluates util.Haversine on an array (the device probe here, the C oracle in the tests)."""
+    Ny, Nx = lat.shape
+    j_prv, i_prv = int(ji_prv[0]), int(ji_prv[1])
+    j1, j2 = max(j_prv - np_box_r, 0), min(j_prv + np_box_r + 1, Ny)
+    i1, i2 = max(i_prv - np_box_r, 0), min(i_prv + np_box_r + 1, Nx)
+    jy = jx = -1
+    found, rfnd, igo = False, rd_found_km, 0
+    while not found and igo < max_itr:
+        igo += 1
+        if igo > 1:
+            j1, i1, j2, i2 = 0, 0, Ny, Nx                 # the whole domain from the second pass on
+        xd = np.asarray(haversine(pntGcoor[0], pntGcoor[1], np.ascontiguousarray(lat[j1:j2, i1:i2]), np.ascontiguousarray(lon[j1:j2, i1:i2])))
+        jy, jx = (int(k) for k in np.unravel_index(np.argmin(xd), xd.shape))      # first minimum in C order (find_ji_of_min, :13-20)
+        if igo == 1 and res is not None:
+            rfnd = 0.5 * res[jy, jx]
+        found = bool(xd[jy, jx] < rfnd)
+        if igo > 1 and not found:
+            rfnd = 1.2 * rfnd
+    jy, jx = jy + j1, jx + i1
+    if jy < 0 or jx < 0 or jy >= Ny or jx >= Nx or igo == max_itr:
+        return (-1, -1)
+    return (jy, jx)
+
+
 def NearestPoint(pntGcoor, pLat, pLon, rd_found_km=10., resolkm=[], ji_prv=(), np_box_r=10, max_itr=5, ctx=None):
     """reference locate.py:222-276: (j,i) of the grid point nearest to `pntGcoor` = (lat,lon), (-1,-1) if the acceptance
-    loop gives up.  Whole-domain search only, as SeedInit uses it: the `ji_prv` / `np_box_r` local-box variant is not
-    offered (ValueError)."""
-    if len(ji_prv) != 0:
-        raise ValueError("NearestPoint: the local search around ji_prv is not part of this build (SeedInit does not use it)")
+    loop gives up.  Whole-domain search (as SeedInit uses it) through the device's bounding-sphere search; with a previous
+    position `ji_prv` (round 4) the reference's box-then-domain passes, the distances evaluated on the device."""
     lat = np.ascontiguousarray(pLat, dtype=np.float64)
     lon = np.ascontiguousarray(pLon, dtype=np.float64)
     if lon.shape != lat.shape:
         print('ERROR [NearestPoint]: `pLat` & `pLon` do not have the same shape!')
         raise SystemExit(0)
+    res = np.asarray(resolkm, dtype=np.float64) if np.shape(resolkm) == lat.shape else None       # `l2Dresol` of the reference
     c = ctx if ctx is not None else _scratch()
+    if len(ji_prv) == 2:
+        return nearest_point_with_previous(lambda a, b, x, y: c.eval_haversine(float(a), float(b), x, y), (float(pntGcoor[0]), float(pntGcoor[1])),
+                                           lat, lon, rd_found_km, res, ji_prv, int(np_box_r), int(max_itr))
     if ctx is None:
         z = np.zeros(lat.shape)
         c.set_grid(z, z, z, z, z, z, np.ones(lat.shape, dtype=np.int8))
-    res = np.asarray(resolkm, dtype=np.float64) if np.shape(resolkm) == lat.shape else None       # `l2Dresol` of the reference
     ji, _ = c.nearest_point(np.array([[float(pntGcoor[0]), float(pntGcoor[1])]]), lat, lon, res, rd_found_km, max_itr)
     return (int(ji[0, 0]), int(ji[0, 1]))
 

@@ -333,6 +333,43 @@ def g5b_seedinit_on_points():
 
 
 # --------------------------------------------------------------------------- G5c
+def g5d_nearest_point_local_box():
+    """G5d: `NearestPoint` with a previous position (`ji_prv`, `np_box_r`; locate.py:241-245,253-268) -- the local-box variant the
+    tracker itself never uses (SeedInit passes no `ji_prv`, tracking.py:134) but the function offers: first pass over the box around
+    `ji_prv` (with `resolkm` indexed by the BOX-relative minimum, as the reference does), whole domain from the second pass on.
+    On G5's mesh: the true neighbourhood, a previous cell far away (falls back to the whole domain), boxes cut by the domain's
+    edges, with and without the 2-D resolution, several box radii and iteration limits, points outside the mesh."""
+    g5 = dict(np.load(os.path.join(HERE, "g5_seedinit.npz")))
+    latT, lonT, resol, pSG = g5["latT"], g5["lonT"], g5["resol"], g5["pSG"]
+    Nj, Ni = latT.shape
+    rng = np.random.default_rng(1242)
+    cases, outs = [], []
+    for k in range(0, len(pSG), 2):
+        near = g5["nearest"][k]
+        jj, ii = (int(near[0]), int(near[1])) if near[0] >= 0 else (int(rng.integers(0, Nj)), int(rng.integers(0, Ni)))
+        mode = int(rng.integers(0, 4))
+        if mode == 0:                                   # previous cell a few cells away: found in the box
+            prv = (int(np.clip(jj + rng.integers(-4, 5), 0, Nj - 1)), int(np.clip(ii + rng.integers(-4, 5), 0, Ni - 1)))
+        elif mode == 1:                                 # far away: the box misses, whole domain from pass 2
+            prv = (int(rng.integers(0, Nj)), int(rng.integers(0, Ni)))
+        elif mode == 2:                                 # a corner of the domain: the box is cut
+            prv = (int(rng.choice([0, 1, Nj - 2, Nj - 1])), int(rng.choice([0, 1, Ni - 2, Ni - 1])))
+        else:
+            prv = (jj, ii)
+        box_r = int(rng.choice([1, 3, 10]))
+        max_itr = int(rng.choice([2, 3, 5, 10]))
+        use_res = bool(rng.random() < 0.6)
+        rd = float(rng.choice([2.5, 8.0, 30.0]))
+        with quiet():
+            jy, jx = locate.NearestPoint((pSG[k, 0], pSG[k, 1]), latT, lonT, rd_found_km=rd, resolkm=(resol if use_res else []),
+                                         ji_prv=prv, np_box_r=box_r, max_itr=max_itr)
+        cases.append([k, prv[0], prv[1], box_r, max_itr, int(use_res), rd])
+        outs.append([jy, jx])
+    outs = np.array(outs, dtype=np.int64)
+    print("   G5d: %d cases, %d not found, %d found" % (len(outs), int((outs[:, 0] < 0).sum()), int((outs[:, 0] >= 0).sum())))
+    save("g5d_nearest_local.npz", cases=np.array(cases, dtype=np.float64), ji=outs)
+
+
 def g5c_seedinit_larger_mesh():
     """`SeedInit` / `NearestPoint` of the reference on a mesh large enough for the device search's bounding-sphere hierarchy
     (16 x 16-point blocks, 16 x 16-block superblocks): 300 x 330 T-points around the pole (the pole is INSIDE the mesh: longitudes
@@ -682,7 +719,7 @@ def g10_nemoseed():
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, fn in (("g1", g1_inside), ("g2", g2_intersect), ("g3", g3_crossing), ("g4", g4_survive), ("g4b", g4b_survive_wide),
-                     ("g5", g5_seedinit), ("g5b", g5b_seedinit_on_points), ("g5c", g5c_seedinit_larger_mesh), ("g6", g6_trajectories), ("g6b", g6b_fast_flow_trajectories), ("g6cd", g6cd_baseline_cuts),
+                     ("g5", g5_seedinit), ("g5b", g5b_seedinit_on_points), ("g5c", g5c_seedinit_larger_mesh), ("g5d", g5d_nearest_point_local_box), ("g6", g6_trajectories), ("g6b", g6b_fast_flow_trajectories), ("g6cd", g6cd_baseline_cuts),
                      ("g7", g7_projection), ("g8", g8_timespan),
                      ("g9", g9_haversine), ("g10", g10_nemoseed)):
         if not only or name in only:

@@ -242,6 +242,20 @@ def test_g6cd_reference_trajectories_on_the_baseline_workloads(golden, name):
         assert tr.ncross > 0.05 * Nt * len(yx0)
 
 
+def test_g5d_nearest_point_with_a_previous_position(golden):
+    """G5d: the reference's `NearestPoint` with `ji_prv` / `np_box_r` (locate.py:241-271; off the tracker's path -- SeedInit passes no
+    previous position -- but part of the function): the host logic of sitrack_amd/predicates.py over the oracle's Haversine reproduces
+    the reference's 210 answers, found and given up alike, incl. the box-relative index into `resolkm` of the first pass."""
+    from sitrack_amd.predicates import nearest_point_with_previous
+    g, d = golden("g5_seedinit.npz"), golden("g5d_nearest_local.npz")
+    assert (d["ji"][:, 0] < 0).sum() > 20 and (d["ji"][:, 0] >= 0).sum() > 100
+    for (k, pj, pi, box_r, max_itr, use_res, rd), want in zip(d["cases"], d["ji"]):
+        k = int(k)
+        got = nearest_point_with_previous(orc.Haversine, (g["pSG"][k, 0], g["pSG"][k, 1]), g["latT"], g["lonT"], float(rd),
+                                          g["resol"] if use_res else None, (int(pj), int(pi)), int(box_r), int(max_itr))
+        assert got == tuple(want), (k, got, tuple(want))
+
+
 def test_g7_forward_projection_matches_reference_fixture(golden):
     # tools/nc/sitrack_seeding_sidfex_19961215_00_HSS5.nc__KEEP: (lat,lon) f4 -> (y_pos,x_pos) f4 made by the
     # reference's cartopy forward projection from tools/sidfexloc.dat

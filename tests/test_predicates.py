@@ -78,8 +78,13 @@ def test_nearest_point_and_haversine_scalars(sit, golden):
                       for k in range(0, len(g["ids"]), 7)])
     assert np.array_equal(plain, g["nearest_plain"])
     assert (g["nearest"] < 0).any() and (g["nearest_plain"] < 0).any()            # both outcomes are in the vectors
-    with pytest.raises(ValueError):
-        sit.NearestPoint((80., 10.), g["latT"], g["lonT"], ji_prv=(3, 4))
+    # round 4: with a previous position (`ji_prv`, `np_box_r`): the reference's box-then-domain passes, G5d from the reference
+    d = golden("g5d_nearest_local.npz")
+    for (k, pj, pi, box_r, max_itr, use_res, rd), want in zip(d["cases"], d["ji"]):
+        k = int(k)
+        got = sit.NearestPoint((g["pSG"][k, 0], g["pSG"][k, 1]), g["latT"], g["lonT"], rd_found_km=float(rd),
+                               resolkm=(g["resol"] if use_res else []), ji_prv=(int(pj), int(pi)), np_box_r=int(box_r), max_itr=int(max_itr))
+        assert got == tuple(want), (k, got, tuple(want))
     # the whole batch through the context method: indices and distances
     ctx = sit.Context(0)
     z = np.zeros_like(g["latT"])
