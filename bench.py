@@ -1117,7 +1117,13 @@ def main():
                 out["lane_utilisation_note"] = ("(%.0f main-path instructions x 64 lanes + %.0f crossing-path instructions x %.1f lanes) / "
                                                 "(all instructions x 64): %.3f of the buoy-records leave their cell (%s)"
                                                 % (main_i, cross_i, 64 * p_cross, p_cross, p_cross_src))
-            if ipwr:
+            died = 1.0 - nalive / float(nP * world)
+            if ipwr and died > 0.02:
+                # dead buoys' lanes (and whole waves of them) stop issuing: the per-wave instruction count of the profiled run no
+                # longer describes this one -- no fraction is claimed
+                out.update({"achieved": None, "frac": None, "frac_note": "%.0f %% of the buoys died during the run: the instruction count per "
+                            "wave and record of the counter profile (%s buoys alive throughout) does not describe it" % (100 * died, "nearly all")})
+            elif ipwr:
                 ach = ipwr * nwaves / rec_s / 1e9
                 out.update({"achieved": ach, "frac": None if stale else ach / peak,
                             "frac_uniform_4_cycles": None if stale else ach / VALU_PEAK_GINST,
