@@ -134,7 +134,7 @@ def nearest_point_with_previous(haversine, pntGcoor, lat, lon, rd_found_km, res,
     """`NearestPoint` with a previous position (reference locate.py:241-271): the first pass searches the box of `np_box_r` points
     around `ji_prv`, every later pass the whole domain; the acceptance radius starts at 0.5 * resolkm[jy, jx] -- indexed, like the
     reference, by the minimum's position INSIDE THE BOX -- or at `rd_found_km`, and grows by 20 % per failed pass after the first.
-    `haversine(plat, plon, xlat, xlon)` evaluates util.Haversine on an array (the device probe here, the C oracle in the tests)."""
+    `haversine(plat, plon, xlat, xlon)` evaluates util.Haversine on an array (the device probe here; the CPU tests pass their own)."""
     Ny, Nx = lat.shape
     j_prv, i_prv = int(ji_prv[0]), int(ji_prv[1])
     j1, j2 = max(j_prv - np_box_r, 0), min(j_prv + np_box_r + 1, Ny)
