@@ -1028,6 +1028,9 @@ __global__ __launch_bounds__(kRunBlock, WINDOW ? SITRK_RUN_WAVES_WINDOW : SITRK_
             if (jrec > last) break;
         }
         // the four velocity candidates u[jT,iT-1], u[jT,iT], v[jT-1,iT], v[jT,iT]
+#ifdef SITRK_PRIO_LOADS                 // (A/B hook, same results: the record's loads issued at raised wave priority)
+        __builtin_amdgcn_s_setprio(3);
+#endif
 #ifdef SITRK_ABL_VEL2                   // ablation (timing only, WRONG results): two velocity loads instead of three
         FT fu1 = *(const FT *)(ub + x.o1), fu0 = fu1;
         FT fv1 = *(const FT *)(vb + x.o1), fv0 = fv1;
@@ -1040,6 +1043,9 @@ __global__ __launch_bounds__(kRunBlock, WINDOW ? SITRK_RUN_WAVES_WINDOW : SITRK_
         unsigned k9 = 0; (void)kb;
 #else
         unsigned k9 = *(const uint8_t *)(kb + (x.o1 >> (sizeof(FT) == 4 ? 2 : 3)));
+#endif
+#ifdef SITRK_PRIO_LOADS
+        __builtin_amdgcn_s_setprio(0);
 #endif
         double zU, zV;
         FT su = 0, sv = 0;                               // UVS == 1: the selected candidates as loaded
@@ -1098,6 +1104,9 @@ __global__ __launch_bounds__(kRunBlock, WINDOW ? SITRK_RUN_WAVES_WINDOW : SITRK_
         SITRK_STAMP(4)                                   // cell test
 #endif
         if (!still_in) {      // :466-484
+#ifdef SITRK_PRIO_CROSS                 // (A/B hook, same results: the crossing path -- the long part of a wave's chain -- at raised priority)
+            __builtin_amdgcn_s_setprio(2);
+#endif
             const unsigned kcell = x.o1 / (unsigned)sizeof(FT);
             int dcell, dk, dlo = 0;
             pin_load(k9);
@@ -1119,6 +1128,9 @@ __global__ __launch_bounds__(kRunBlock, WINDOW ? SITRK_RUN_WAVES_WINDOW : SITRK_
             inl = patch_covers(pa, crel >> 16, crel & 0xffff);
             if (inl) load_ctx_lds<sizeof(FT)>(a, pa, gb, kcell + (unsigned)dk, lo, x);
             else load_ctx<sizeof(FT)>(a, gb, kcell + (unsigned)dk, x);
+#ifdef SITRK_PRIO_CROSS
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
         P = Pn;
 #ifdef SITRK_DIAG
