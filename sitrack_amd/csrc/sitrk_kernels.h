@@ -904,6 +904,21 @@ __device__ __forceinline__ void resolve_crossing_lds(pt P1, pt P2, pt bl, pt br,
 
 static constexpr int kRunLdsFixed = 256 + 256 + 64;      // crossing table, its LDS-offset twin (same row stride), bounding box / patch header
 
+// Wave priorities inside the fused loop (s_setprio: a scheduling hint, results untouched).  The loop sits where vector issue and
+// the per-wave dependency chain meet; which of the seven waves of a SIMD issues next is the arbiter's choice.
+// Raised priority for the record's loads (they go out before other waves' arithmetic: their latency overlaps more of it) and
+// for the crossing path (the long stretch of a wave's chain, after which it can request its next operands): +1.1 ... +2.2 % on C3,
+// +1.6 % on C2, five interleaved rounds (profiles/r04y_prio_ab.txt); (3,3), (3,1), (1,3), (2,1) are within 0.3 % of (3,2), main
+// path high / the rest low is no better than no hint.  -DSITRK_PRIO_LOADS=0 -DSITRK_PRIO_CROSS=0 builds the loop without the hints.
+#ifndef SITRK_PRIO_LOADS
+#define SITRK_PRIO_LOADS 3
+#endif
+#ifndef SITRK_PRIO_CROSS
+#define SITRK_PRIO_CROSS 2
+#endif
+#ifndef SITRK_PRIO_BASE
+#define SITRK_PRIO_BASE 0
+#endif
 #ifndef SITRK_RUN_BLOCK
 #define SITRK_RUN_BLOCK 256             // workgroup size of the fused kernel (A/B: tools/build_variant.sh x -DSITRK_RUN_BLOCK=128 ...)
 #endif
@@ -1028,8 +1043,8 @@ __global__ __launch_bounds__(kRunBlock, WINDOW ? SITRK_RUN_WAVES_WINDOW : SITRK_
             if (jrec > last) break;
         }
         // the four velocity candidates u[jT,iT-1], u[jT,iT], v[jT-1,iT], v[jT,iT]
-#ifdef SITRK_PRIO_LOADS                 // (A/B hook, same results: the record's loads issued at raised wave priority)
-        __builtin_amdgcn_s_setprio(3);
+#if SITRK_PRIO_LOADS > 0                // the record's loads issued at raised wave priority
+        __builtin_amdgcn_s_setprio(SITRK_PRIO_LOADS);
 #endif
 #ifdef SITRK_ABL_VEL2                   // ablation (timing only, WRONG results): two velocity loads instead of three
         FT fu1 = *(const FT *)(ub + x.o1), fu0 = fu1;
@@ -1044,8 +1059,8 @@ __global__ __launch_bounds__(kRunBlock, WINDOW ? SITRK_RUN_WAVES_WINDOW : SITRK_
 #else
         unsigned k9 = *(const uint8_t *)(kb + (x.o1 >> (sizeof(FT) == 4 ? 2 : 3)));
 #endif
-#ifdef SITRK_PRIO_LOADS
-        __builtin_amdgcn_s_setprio(0);
+#if SITRK_PRIO_LOADS > 0
+        __builtin_amdgcn_s_setprio(SITRK_PRIO_BASE);
 #endif
         double zU, zV;
         FT su = 0, sv = 0;                               // UVS == 1: the selected candidates as loaded
@@ -1104,8 +1119,8 @@ __global__ __launch_bounds__(kRunBlock, WINDOW ? SITRK_RUN_WAVES_WINDOW : SITRK_
         SITRK_STAMP(4)                                   // cell test
 #endif
         if (!still_in) {      // :466-484
-#ifdef SITRK_PRIO_CROSS                 // (A/B hook, same results: the crossing path -- the long part of a wave's chain -- at raised priority)
-            __builtin_amdgcn_s_setprio(2);
+#if SITRK_PRIO_CROSS > 0                // the crossing path -- the long part of a wave's chain -- at raised priority
+            __builtin_amdgcn_s_setprio(SITRK_PRIO_CROSS);
 #endif
             const unsigned kcell = x.o1 / (unsigned)sizeof(FT);
             int dcell, dk, dlo = 0;
@@ -1128,8 +1143,8 @@ __global__ __launch_bounds__(kRunBlock, WINDOW ? SITRK_RUN_WAVES_WINDOW : SITRK_
             inl = patch_covers(pa, crel >> 16, crel & 0xffff);
             if (inl) load_ctx_lds<sizeof(FT)>(a, pa, gb, kcell + (unsigned)dk, lo, x);
             else load_ctx<sizeof(FT)>(a, gb, kcell + (unsigned)dk, x);
-#ifdef SITRK_PRIO_CROSS
-            __builtin_amdgcn_s_setprio(0);
+#if SITRK_PRIO_CROSS > 0
+            __builtin_amdgcn_s_setprio(SITRK_PRIO_BASE);
 #endif
         }
         P = Pn;
