@@ -73,9 +73,31 @@ int main(void)
         CHK(sitrk_step(h, 2, 0));                                  /* rows 2..13 cover [5-2, 10+3) */
         CHK(sitrk_fetch(h, o2, NULL, NULL, NULL));
         if (memcmp(o2, out, sizeof(out))) { printf("row-band record differs from whole record\n"); return 1; }
+        /* round 4: the same record as a BOX (rows x columns the buoys can touch), out of whole fields (ld = N), into the third slot */
+        {
+            int32_t imin, imax, age = -1;
+            float *fu = (float *)malloc(sizeof(float) * N * N), *fv = (float *)malloc(sizeof(float) * N * N), *fs = (float *)malloc(sizeof(float) * N * N);
+            for (int k = 0; k < N * N; k++) { fu[k] = 0.5f; fv[k] = -0.25f; fs[k] = 1.0f; }
+            CHK(sitrk_set_buoys(h, 3, yx, ji, NULL, NULL));
+            CHK(sitrk_buoy_box(h, &jmin, &jmax, &imin, &imax));
+            if (jmin != 5 || jmax != 10 || imin != 5 || imax != 8) { printf("buoy box %d..%d x %d..%d\n", jmin, jmax, imin, imax); return 1; }
+            const int j0 = jmin - 2, j1 = jmax + 3, i0 = imin - 2, i1 = imax + 3;
+            CHK(sitrk_push_record_box(h, 2, j0, j1, i0, i1, fu + j0 * N + i0, fv + j0 * N + i0, fs + j0 * N + i0, N));
+            memset(fu, 0xff, sizeof(float) * N * N); free(fu); free(fv); free(fs);          /* the caller's arrays are its own again */
+            CHK(sitrk_buoy_box_begin(h));                              /* (the asynchronous form: queued, collected later) */
+            CHK(sitrk_step(h, 2, 0));
+            CHK(sitrk_buoy_box_end(h, &jmin, &jmax, &imin, &imax, &age));
+            if (age != 1 || jmin != 5 || imax != 8) { printf("async box: age %d rows from %d columns to %d\n", age, jmin, imax); return 1; }
+            CHK(sitrk_fetch(h, o2, NULL, NULL, NULL));
+            if (memcmp(o2, out, sizeof(out))) { printf("box record differs from whole record\n"); return 1; }
+            if (sitrk_step(h, 2, 1) != SITRK_EINVAL) { printf("a box one cell too narrow must be refused\n"); return 1; }
+            CHK(sitrk_commit_records_box(h, 0, 2, 2, N - 2, 2, N - 2));   /* slots 0 and 1 hold whole records: commit a box of them, one launch */
+            CHK(sitrk_commit_records_box_async(h, 0, 2, 2, N - 2, 2, N - 2));
+            CHK(sitrk_sync(h));
+        }
         int64_t nf = -1, nr = -1, ns = -1;
         CHK(sitrk_launch_stats(h, 1, &nf, &nr, &ns));
-        if (nf != 0 || nr != 0 || ns != 3) { printf("launch stats %lld %lld %lld\n", (long long)nf, (long long)nr, (long long)ns); return 1; }
+        if (nf != 0 || nr != 0 || ns != 4) { printf("launch stats %lld %lld %lld\n", (long long)nf, (long long)nr, (long long)ns); return 1; }
     }
     for (int p = 0; p < 3; p++) {
         /* dx = 0.5*3600/1000 = 1.8 km, dy = -0.9 km, exactly as the reference computes them */
