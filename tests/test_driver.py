@@ -516,6 +516,44 @@ def test_cli_end_to_end_vs_oracle(tmp_path, monkeypatch, two_d_time):
     assert np.array_equal(out2["vJIt"], out["vJIt"]) and np.array_equal(out2["iAlive"], out["iAlive"])
 
 
+@pytest.mark.parametrize("backend", ["hdf5", "netcdf3"])
+def test_stream_writer_equals_the_whole_array_writer(tmp_path, monkeypatch, backend):
+    """`ncio.CloudBuoysStream` (records appended one at a time: what the driver's `-F` does) against `ncSaveCloudBuoys` (whole arrays:
+    what the reference does, ncio.py:131-197): the same file, variable for variable -- through libhdf5 (NetCDF-4, incl. rows wide enough
+    for the thread-pool chunk path) and through the NetCDF-3 fall-back writer."""
+    from sitrack_amd import h5lite
+    if backend == "netcdf3":
+        monkeypatch.setattr(h5lite, "writer_available", lambda: False)
+    elif not h5lite.writer_available():
+        pytest.skip("no libhdf5 here")
+    Nt, Nb = 6, 70_000 if backend == "hdf5" else 3_000
+    rng = np.random.default_rng(1)
+    t = np.arange(Nt) * 3600 + 850608000
+    ids = np.arange(Nb) + 300534062025510 if backend == "hdf5" else np.arange(Nb) + 900120
+    Y, X = rng.normal(size=(Nt, Nb)) * 1000, rng.normal(size=(Nt, Nb)) * 1000
+    La, Lo = rng.uniform(60, 90, (Nt, Nb)), rng.uniform(-180, 180, (Nt, Nb))
+    M = (rng.random((Nt, Nb)) > 0.1).astype('i1')
+    fa, fb = str(tmp_path / "whole.nc"), str(tmp_path / "stream.nc")
+    ncio.ncSaveCloudBuoys(fa, t, ids, Y, X, La, Lo, mask=M, corigin='X')
+    st = ncio.CloudBuoysStream(fb, t, ids, corigin='X', flush_bytes=1 << 20)
+    with pytest.raises(IndexError):
+        st.put(Nt, Y[0], X[0], La[0], Lo[0], M[0])
+    for k in range(Nt):
+        st.put(k, Y[k], X[k], La[k], Lo[k], M[k])
+    st.close()
+    assert open(fa, 'rb').read(4) == open(fb, 'rb').read(4) == (b'\x89HDF' if backend == "hdf5" else b'CDF\x02')
+    ra, rb = ncio.LoadNCdata(fa, krec=-1, lmask=True), ncio.LoadNCdata(fb, krec=-1, lmask=True)
+    assert all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(ra, rb))
+    if backend == "hdf5":
+        assert os.path.getsize(fa) == os.path.getsize(fb)
+    # a stream that is closed before every record was written does not leave a half-written file behind
+    st = ncio.CloudBuoysStream(str(tmp_path / "short.nc"), t, ids)
+    st.put(0, Y[0], X[0], La[0], Lo[0], M[0])
+    with pytest.raises(ValueError):
+        st.close()
+    assert not os.path.exists(str(tmp_path / "short.nc"))
+
+
 @pytest.mark.gpu
 def test_cli_F_streams_the_series_in_bounded_memory_and_out_stride(tmp_path, monkeypatch):
     """`-F` at a size where the reference's way would not fit a laptop: >= 1e6 buoys x 200 hourly records.  The reference holds the
