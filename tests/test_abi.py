@@ -209,3 +209,41 @@ def test_roofline_goes_stale_when_the_kernel_changes():
     edited = dict(shipped, sha256="0" * 16)
     assert bench.roofline_is_stale(edited, shipped) is True and bench.roofline_is_stale(None, shipped) is True
     assert bench.roofline_is_stale(shipped, None) is True
+
+
+def test_box_arithmetic_of_the_binding():
+    """`Context.box_of`: the box a record's next steps can touch from the buoys' extreme host cells -- [jmin-2-age, jmax+3+age) x
+    [imin-2-age, imax+3+age), clipped to the mesh, columns widened to 16-byte lines (host arithmetic only: no device needed)."""
+    class Mesh:
+        Nj, Ni = 100, 64
+    box_of = _lib.Context.box_of
+    assert box_of(Mesh, 10, 20, 9, 30, 0) == (8, 23, 4, 36)            # columns [7, 33) -> [4, 36)
+    assert box_of(Mesh, 10, 20, 10, 29, 0, align=1) == (8, 23, 8, 32)
+    assert box_of(Mesh, 10, 20, 9, 30, 5) == (3, 28, 0, 40)
+    assert box_of(Mesh, 1, 98, 1, 62, 0) == (0, 100, 0, 64)            # clipped
+    assert box_of(Mesh, 50, 50, 61, 62, 7) == (41, 60, 52, 64)
+    assert box_of(Mesh, 1, 0, 1, 0, 3) == (0, 0, 0, 0)                 # no live buoy
+
+
+def test_kernel_fingerprints_are_written_next_to_the_library():
+    """the build leaves the fingerprint of the kernels as shipped next to libsitrk.so (tools/kernel_fingerprint.py): what bench.py
+    ties its roofline constants to"""
+    import json
+    _lib.build()
+    d = json.load(open(os.path.splitext(_lib.SO_PATH)[0] + ".isa.json"))
+    assert d["arch"] == "gfx950" and len(d["kernels"]) == 4
+    for name, k in d["kernels"].items():
+        assert k is not None and len(k["sha256"]) == 16 and k["static"]["valu"] > 50 and k["code_bytes"] > 1000, name
+    fused = d["kernels"]["advect_run_kernel<float,1,false>"]["static"]
+    assert fused["valu64"] > 0.4 * fused["valu"] and fused["lds"] > 10 and fused["vmem"] > 10
+
+
+def test_nearest_t_index_agrees_with_the_tree_on_warped_meshes():
+    """`synthetic.nearest_t_index` (what bench.py seeds 1e7 buoys on curvilinear meshes with, as the guess of FindContainingCell) against
+    the k-d tree: the same T-point, or a direct neighbour where two are nearly equidistant"""
+    from sitrack_amd import synthetic as syn
+    for g in (syn.make_grid(300, 260, dkm=4.0, warp=1.0), syn.shift_grid(syn.make_grid(566, 492, dkm=12.5, warp=1.0), -250., 150.)):
+        rng = np.random.default_rng(2)
+        yx = np.stack([rng.uniform(g["Yt"].min() + 30, g["Yt"].max() - 30, 20000), rng.uniform(g["Xt"].min() + 30, g["Xt"].max() - 30, 20000)], axis=1)
+        a, b = syn.nearest_t_plane(g, yx), syn.nearest_t_index(g, yx)
+        assert np.abs(a - b).max() <= 1 and (a != b).any(axis=1).mean() < 0.02
