@@ -765,6 +765,52 @@ def test_box_ingest_equals_full_ingest(fdt, Ni, tile, mode):
     assert not np.isnan(res["box"]["yx"]).any() and 0 < res["box"]["iAlive"].sum() < len(res["box"]["iAlive"])
 
 
+@pytest.mark.parametrize("on_ingest", [False, True])
+def test_batched_box_commit_of_twelve_records(on_ingest):
+    """`sitrk_commit_records_box` on a batch larger than the tests of the fused launch use elsewhere (3 records): twelve slabs written whole into device memory with everything outside the box poisoned, their stale
+    Survive bytes those of an ice-free record, ONE commit for all twelve, one fused launch of twelve records -- against the oracle."""
+    import torch
+    from sitrack_amd import distributed as sd
+    Nj, Ni, K = 150, 256, 12
+    grid = syn.make_grid(Nj, Ni, dkm=4.0, warp=1.0)
+    u, v, sic = syn.make_fields(grid, K=K, seed=31, umax=1.0, drift=0.6, ripple=0.1)
+    tmask = grid["tmask"].copy(); tmask[70:74, 100:130] = 0
+    for k in range(K):
+        sic[k, 40:52, 60 + 3 * k:90 + 3 * k] = 0.03
+    _, yx = syn.make_buoys(grid, 40000, seed=5, frac=0.9)
+    yx = yx[(np.abs(yx[:, 0]) < 150.) & (np.abs(yx[:, 1]) < 300.)]
+    trk = make_tracker(grid, tmask, K)
+    try:
+        ctx = trk.ctx
+        found, ji, _ = sit.FindContainingCell(yx, syn.nearest_t_plane(grid, yx), ctx=ctx)
+        yx, ji = yx[found], ji[found]
+        trk.set_buoys(yx, ji)
+        zero = np.zeros((Nj, Ni), dtype=np.float32)
+        for k in range(K):
+            ctx.push_record(k, zero, zero, zero)                  # every Survive byte of every slot: kill
+        box = ctx.box(K - 1)
+        assert (box[1] - box[0]) * (box[3] - box[2]) < 0.8 * Nj * Ni
+        ctx.sync()
+        for k in range(K):
+            comp = [np.full((Nj, Ni), np.nan, dtype=np.float32), np.full((Nj, Ni), np.nan, dtype=np.float32), zero.copy()]
+            for dst, src in zip(comp, (u[k], v[k], sic[k])):
+                dst[box[0]:box[1], box[2]:box[3]] = src[box[0]:box[1], box[2]:box[3]]
+            sd.slot_tensor(ctx, k).copy_(torch.from_numpy(sd.pack_slab(*comp, np.float32)))
+        torch.cuda.synchronize()
+        ctx.commit_records_box(0, K, *box, on_ingest_stream=on_ingest)
+        ctx.set_tuning(fuse=K)
+        ctx.run(0, 0, K)
+        st = trk.state()
+        g2 = dict(grid); g2["tmask"] = tmask
+        ref = orc.Tracker(g2, yx, ji, nthreads=4)
+        for k in range(K):
+            ref.step(k, u[k].astype(np.float64), v[k].astype(np.float64), sic[k].astype(np.float64), want_out=False)
+        assert np.array_equal(st["yx"], ref.pos) and np.array_equal(st["vJIt"], ref.jiT) and np.array_equal(st["iAlive"], ref.alive)
+        assert 0 < (ref.alive == 0).sum() < len(yx) and ctx.launch_stats()["fused_launches"] == 1
+    finally:
+        trk.close()
+
+
 def test_survive_bytes_of_a_box_equal_those_of_the_whole_record(ctx):
     """The Survive bytes a box commit derives are those of the whole-record pass wherever the box determines them, for boxes at
     every alignment of their four edges, through the trajectories' own reader of the bytes: a cloud stepped once per box."""
