@@ -664,8 +664,9 @@ SITRK_API int sitrk_push_record(sitrk_t *h, int slot, const void *u, const void 
 static int eval_buoy_box(sitrk_ctx *h)
 {
     h->box_pending = false;             // a synchronous evaluation supersedes one that was begun and not collected
-    h->band_jmin = 1; h->band_jmax = 0; h->band_imin = 1; h->band_imax = 0; h->band_age = 0;
-    if (h->nP == 0) return SITRK_OK;
+    h->band_jmin = 1; h->band_jmax = 0; h->band_imin = 1; h->band_imax = 0;
+    h->band_age = -1;                   // no box is known until this evaluation has succeeded (check_band refuses partial slots meanwhile)
+    if (h->nP == 0) { h->band_age = 0; return SITRK_OK; }
     NEED(h->st[0].pos, "sitrk_buoy_rows: call sitrk_set_buoys first");
     HIPCHK(hipSetDevice(h->device));
     int res[4];
@@ -676,6 +677,7 @@ static int eval_buoy_box(sitrk_ctx *h)
     HIPCHK(hipMemcpyAsync(res, d, sizeof(res), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (res[0] >= 0) { h->band_jmax = res[0]; h->band_jmin = -res[1]; h->band_imax = res[2]; h->band_imin = -res[3]; }
+    h->band_age = 0;
     return SITRK_OK;
 }
 
@@ -709,8 +711,8 @@ SITRK_API int sitrk_buoy_box_begin(sitrk_t *h)
     NEED(h, "null handle");
     NEED(!h->box_pending, "sitrk_buoy_box_begin: the evaluation begun before was not collected (sitrk_buoy_box_end)");
     h->box_host[0] = -1; h->box_host[1] = 0; h->box_host[2] = -1; h->box_host[3] = 0;      // {max j, max -j, max i, max -i}: none alive
-    h->box_pending = true; h->box_pending_age = 0;
-    if (h->nP == 0) return SITRK_OK;
+    h->box_pending_age = 0;
+    if (h->nP == 0) { h->box_pending = true; return SITRK_OK; }
     NEED(h->st[0].pos, "sitrk_buoy_box_begin: call sitrk_set_buoys first");
     HIPCHK(hipSetDevice(h->device));
     int *d = (int *)h->counter + 4;                                 // second half of the 32-byte reduction scratch
@@ -719,6 +721,7 @@ SITRK_API int sitrk_buoy_box_begin(sitrk_t *h)
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h->box_host, d, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipEventRecord(h->box_ev, h->stream));
+    h->box_pending = true;              // only now: an evaluation that failed to queue leaves nothing to collect
     return SITRK_OK;
 }
 
