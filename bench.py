@@ -1118,7 +1118,12 @@ def main():
                                                 "(all instructions x 64): %.3f of the buoy-records leave their cell (%s)"
                                                 % (main_i, cross_i, 64 * p_cross, p_cross, p_cross_src))
             died = 1.0 - nalive / float(nP * world)
-            if ipwr and died > 0.02:
+            if ipwr and a.uv_strategy != 1:
+                # the counter passes are of advect_run_kernel<float, 1, false> (the reference's default rule): another instantiation ran
+                out.update({"achieved": None, "frac": None, "frac_note": "iUVstrategy = %d runs another instantiation of the kernel than the "
+                            "profiled one (iUVstrategy = 1): its instruction count per wave and record is not known, no fraction is claimed"
+                            % a.uv_strategy})
+            elif ipwr and died > 0.02:
                 # dead buoys' lanes (and whole waves of them) stop issuing: the per-wave instruction count of the profiled run no
                 # longer describes this one -- no fraction is claimed
                 out.update({"achieved": None, "frac": None, "frac_note": "%.0f %% of the buoys died during the run: the instruction count per "

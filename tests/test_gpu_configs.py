@@ -81,6 +81,16 @@ def test_c3_full_1000_steps_checked_by_the_oracle():
     assert e["box"]["particle_steps_per_s"] > e["whole_record"]["particle_steps_per_s"] > 1e9
 
 
+def test_c3_cell_mean_rule_claims_no_issue_fraction():
+    """`iUVstrategy = 0` runs another instantiation of the fused kernel than the one the committed counter passes describe: the
+    line carries the throughput (oracle-checked) and withholds `roofline.frac` instead of pricing it with the wrong instruction count"""
+    d, err = _bench(["--uv-strategy", "0", "--records", "8", "--fuse", "8", "--steps", "64", "--warmup", "8", "--only-fused", "--check",
+                     "--no-cpu-baseline", "--no-c2"])
+    assert "check OK" in err, err[-2000:]
+    r = d["roofline"]
+    assert d["value"] > 1e10 and r["frac"] is None and r["achieved"] is None and "iUVstrategy = 0" in r["frac_note"]
+
+
 @pytest.fixture(scope="module")
 def c4():
     from bench import CONFIGS
