@@ -541,12 +541,12 @@ def _memcpy2d_h2d(dst, dpitch, src, spitch, width, height, stream):
         raise RuntimeError("hipMemcpy2DAsync -> %d" % rc)
 
 
-def isa_fingerprint():
-    """fingerprint of the fused kernel in the library that is loaded (written by the build: tools/kernel_fingerprint.py)"""
+def isa_fingerprint(kernel="advect_run_kernel<float,1,false>"):
+    """fingerprint of a kernel (default: the fused one) in the library that is loaded (written by the build: tools/kernel_fingerprint.py)"""
     try:
         import sitrack_amd._lib as L
         d = json.load(open(os.path.splitext(L.SO_PATH)[0] + ".isa.json"))
-        return d["kernels"]["advect_run_kernel<float,1,false>"]
+        return d["kernels"][kernel]
     except Exception:                                                # noqa: BLE001
         return None
 
@@ -1057,9 +1057,12 @@ def main():
         def roofline_step(ms_per_launch):
             """advect_step_kernel: one record per launch, HBM bound (SURVEY 8d's byte model, needed cells only)"""
             s_ = ms_per_launch / 1e3
-            tr = prof_step.get("hbm_bytes_per_launch") if a.buoys == 0 else None
+            tr = prof_step.get("hbm_bytes_per_launch") if (a.buoys == 0 and a.uv_strategy == 1) else None
+            # `achieved` / `frac` are algorithmic bytes over the time measured in THIS run; only `traffic` comes from a counter profile,
+            # and is marked when that profile is of another build of the kernel than the one that ran
             return {"bound": "hbm", "achieved": A1 / s_ / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": A1 / s_ / 1e9 / HBM_PEAK_GBS,
                     "traffic": tr, "traffic_source": prof_step.get("source") if tr else None,
+                    "traffic_stale": roofline_is_stale(prof_step.get("isa"), isa_fingerprint("advect_step_kernel<float,1,false,512>")) if tr else None,
                     "algorithmic_bytes_per_launch": A1, "cells_needed": n_cells, "kernel": "advect_step_kernel",
                     "records_per_launch": 1, "avg_launch_ms": ms_per_launch,
                     "survey_formula_bytes_per_record": A_survey, "survey_formula_frac": A_survey / s_ / 1e9 / HBM_PEAK_GBS}

@@ -68,6 +68,12 @@ def test_c3_full_1000_steps_checked_by_the_oracle():
     assert 2.0 < r["cycles_per_valu_inst"] < 4.0 and abs(r["peak"] - 1024 * 2.4 / r["cycles_per_valu_inst"]) < 1e-6 * r["peak"]
     assert "MODEL" in r["peak_note"] and "fixed per launch" in r["valu_inst_source"] and 190 < r["valu_inst_per_wave_record"] < 230
     assert r["hbm"]["survey_formula_frac"] > 1.0 and r["hbm"]["frac"] < 0.5
+    # the HBM-bound form (one record per launch): algorithmic bytes over THIS run's launch time, at least half of the 8 TB/s; the counter
+    # traffic next to it is tied to the step kernel's own fingerprint
+    pr = d["per_record_launch"]["roofline"]
+    assert pr["bound"] == "hbm" and pr["kernel"] == "advect_step_kernel" and 0.5 < pr["frac"] < 1.0 and isinstance(pr["traffic_stale"], bool)
+    if not pr["traffic_stale"]:
+        assert 0.9 < pr["traffic"] / pr["algorithmic_bytes_per_launch"] < 1.3
     # the Survive derivation inside the clock: every record committed afresh over the box the buoys can touch
     f = d["fresh_records"]
     assert "amortised" not in d["note"] and "OUTSIDE the timed region" in d["note"]

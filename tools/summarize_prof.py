@@ -139,6 +139,8 @@ def main():
         isa_path = os.path.join(src, "libsitrk.isa.json")
         if fused and os.path.exists(isa_path):
             allt[config + "_fused"]["isa"] = json.load(open(isa_path))["kernels"].get("advect_run_kernel<float,1,false>")
+        elif os.path.exists(isa_path):
+            allt[config]["isa"] = json.load(open(isa_path))["kernels"].get("advect_step_kernel<float,1,false,512>")
         for k in ("valu_per_wave_fixed", "valu_per_wave_per_record", "valu_terms_source", "valu64_frac", "valu64_frac_source",
                   "salu_per_wave_fixed", "salu_per_wave_per_record", "valu_main_path_per_wave_record",
                   "valu_crossing_path_per_wave_record", "valu_paths_source", "crossing_rate"):
