@@ -77,25 +77,44 @@ _CUT_CACHE = {}
 
 def baseline_cut_case(g):
     """Golden sets G6c / G6d (the reference's trajectories on the first 10^3 buoys x 100 records of the real C2 / C3 workloads
-    of bench.py): grid, the 32 resident records and the buoys' positions rebuilt from the stored seeds exactly as bench.py builds
-    them, guarded by checksums.  Cached per mesh size (the 4096^2 fields are 6.4 GB)."""
+    of bench.py) and G6e / G6f (the same on bench.py's curvilinear workloads: C3 with `--warp 1.0`, `--config c5shape`): grid, the
+    32 resident records and the buoys' positions rebuilt from the stored seeds exactly as bench.py builds them, guarded by
+    checksums.  Cached per workload (the 4096^2 fields are 6.4 GB)."""
     from sitrack_amd import synthetic as syn
-    Nj, Ni, dkm, warp = g["mesh"]
+    kind = str(g["kind"]) if "kind" in g else "regular"
+    Nj, Ni, dkm, warp = (g["mesh"][k] for k in range(4))
+    Nj, Ni = int(Nj), int(Ni)
     nAll, bseed, nP = (int(x) for x in g["buoys"])
-    K, fseed, umax, drift = g["fields"]
-    key = (int(Nj), int(Ni))
+    K, fseed, umax, drift = g["fields"][:4]
+    key = (Nj, Ni, kind)
     if key not in _CUT_CACHE:
         _CUT_CACHE.clear()
-        grid = syn.make_grid(int(Nj), int(Ni), dkm=float(dkm), warp=float(warp))
-        _, yx = syn.make_buoys(grid, nAll, seed=bseed, frac=0.6)
-        yx0 = np.ascontiguousarray(yx[:nP])
+        grid = syn.make_grid(Nj, Ni, dkm=float(dkm), warp=float(warp))
+        fkw = {}
+        if kind == "c5shape":
+            syn.shift_grid(grid, float(g["mesh"][4]), float(g["mesh"][5]))
+            j0, j1, i0, i1 = (int(x) for x in g["island"])
+            grid["tmask"][j0:j1, i0:i1] = 0
+            rng = np.random.default_rng(bseed)
+            yx = np.stack([rng.uniform(grid["Yt"].min() + 30, grid["Yt"].max() - 30, nAll),
+                           rng.uniform(grid["Xt"].min() + 30, grid["Xt"].max() - 30, nAll)], axis=1)
+            yx0 = np.ascontiguousarray(yx[:int(g["cand_idx"][-1]) + 1].astype(np.float32).astype(np.float64)[g["cand_idx"]])
+            fkw = dict(ripple=float(g["fields"][4]))
+        else:
+            _, yx = syn.make_buoys(grid, nAll, seed=bseed, frac=0.6)
+            yx0 = np.ascontiguousarray(yx[g["cand_idx"]] if kind == "c3warp" else yx[:nP])
         del yx
-        u, v, sic = syn.make_fields(grid, K=int(K), seed=int(fseed), umax=float(umax), drift=float(drift))
-        ok = yx0.sum() == float(g["yx0_sum"]) and (sic == 1).all() and float(g["sic_sum"]) == float(sic.size)
+        u, v, sic = syn.make_fields(grid, K=int(K), seed=int(fseed), umax=float(umax), drift=float(drift), **fkw)
+        if kind == "c5shape":
+            j0, j1, i0, i1 = (int(x) for x in g["polynya"])
+            sic[:, j0:j1, i0:i1] = 0.03
+        ok = yx0.sum() == float(g["yx0_sum"]) and float(g["sic_sum"]) == float(sic.sum(dtype=np.float64))
+        ok = ok and (kind == "c5shape" or (sic == 1).all())
         for q, k in enumerate(g["probe_records"]):
             ok = ok and u[k].astype(np.float64).sum() == g["u_sum"][q] and v[k].astype(np.float64).sum() == g["v_sum"][q]
         assert ok, "the rebuilt workload differs from the one the golden outputs were generated on"
-        assert np.array_equal(syn.regular_host_cell(grid, yx0), g["jiT0"])
+        if kind == "regular":
+            assert np.array_equal(syn.regular_host_cell(grid, yx0), g["jiT0"])
         _CUT_CACHE[key] = (grid, u, v, sic, yx0)
     return _CUT_CACHE[key]
 

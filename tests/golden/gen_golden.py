@@ -650,6 +650,108 @@ def g6cd_baseline_cuts(configs=("c2", "c3"), nP=1000, Nt=100):
         del g, u, v, sic
 
 
+def g6ef_curvilinear_cuts(configs=("c3warp", "c5shape"), nP=1000, Nt=100):
+    """G6e / G6f: REFERENCE trajectories on the two CURVILINEAR workloads of bench.py (round 4: `--warp 1.0`, `--config c5shape`),
+    cut like G6c / G6d to the first 10^3 buoys x 100 records, both velocity rules, with and without record windows.
+      G6e  C3 on the sheared / stretched mesh (warp 1): the buoys of default_rng(1234) in bench.py's order; their host cells from the
+           reference's own FindContainingCell (guess: synthetic.nearest_t_index), the first 10^3 it finds.
+      G6f  the NANUK4-shaped 566 x 492 mesh at 12.5 km with an island and a polynya, flow up to 0.9 m/s: the first candidate seeds of
+           default_rng(1234) (float32 lat/lon + km like a seeding file) through the reference's own SeedInit (NearestPoint by Haversine,
+           Survive, FindContainingCell: tracking.py:98-178), the first 10^3 it keeps; buoys that drift into the open water die.
+    Stored: which candidates the buoys are, their host cells, windows, final state, per-record digests; everything else is rebuilt
+    by the tests from the seeds (conftest.baseline_cut_case) and guarded by checksums."""
+    from oracle import oracle as orc
+    from sitrack_amd.tracking import vertices_of
+    K, kstrt, rdt = 32, 0, 3600.
+    for cfg in configs:
+        extra = {}
+        if cfg == "c3warp":
+            Nj, Ni, nAll, fname = 4096, 4096, 10_000_000, "g6e_c3warp_cut.npz"
+            g = syn.make_grid(Nj, Ni, dkm=4.0, warp=1.0)
+            tmask = g["tmask"]
+            _, yx = syn.make_buoys(g, nAll, seed=1234, frac=0.6)
+            ncand = nP + 50
+            cand = np.ascontiguousarray(yx[:ncand]); del yx
+            guess = syn.nearest_t_index(g, cand)
+            idx, jis = [], []
+            with quiet():
+                for b in range(ncand):
+                    ok, ji, _ = locate.FindContainingCell((cand[b, 0], cand[b, 1]), (int(guess[b, 0]), int(guess[b, 1])), g["Yf"], g["Xf"])
+                    if ok:
+                        idx.append(b); jis.append(ji)
+                    if len(idx) == nP:
+                        break
+            assert len(idx) == nP
+            cand_idx, jiT0 = np.array(idx, dtype=np.int32), np.array(jis, dtype=np.int64)
+            yx0 = np.ascontiguousarray(cand[cand_idx])
+            fpar = dict(seed=2024, umax=0.3, drift=0.05)
+            u, v, sic = syn.make_fields(g, K=K, **fpar)
+            mesh = np.array([Nj, Ni, 4.0, 1.0, 0.0, 0.0])
+            fields = np.array([K, 2024, 0.3, 0.05, 0.0])
+        else:
+            Nj, Ni, nAll, fname = 566, 492, 11_300_000, "g6f_c5shape_cut.npz"
+            g = syn.shift_grid(syn.make_grid(Nj, Ni, dkm=12.5, warp=1.0), -250., 150.)
+            tmask = g["tmask"]
+            isl = (Nj // 3, Nj // 3 + Nj // 12, Ni // 2, Ni // 2 + Ni // 10)
+            pol = (Nj // 2, Nj // 2 + Nj // 10, Ni // 5, Ni // 5 + Ni // 6)
+            tmask[isl[0]:isl[1], isl[2]:isl[3]] = 0
+            rng = np.random.default_rng(1234)
+            yx = np.stack([rng.uniform(g["Yt"].min() + 30, g["Yt"].max() - 30, nAll), rng.uniform(g["Xt"].min() + 30, g["Xt"].max() - 30, nAll)], axis=1)
+            ncand = nP + 200
+            cand = yx[:ncand].astype(np.float32).astype(np.float64); del yx
+            ll = orc.CartNPSkm2Geo1D(np.stack([g["Yt"].ravel(), g["Xt"].ravel()], axis=1))
+            latT, lonT = np.ascontiguousarray(ll[:, 0].reshape(Nj, Ni)), np.ascontiguousarray(np.mod(ll[:, 1], 360.).reshape(Nj, Ni))
+            sll = orc.CartNPSkm2Geo1D(cand); sll[:, 1] = np.mod(sll[:, 1], 360.)
+            sic0 = np.ones((Nj, Ni)); sic0[pol[0]:pol[1], pol[2]:pol[3]] = 0.03
+            ids = np.arange(1, ncand + 1, dtype=np.int64)
+            with quiet():
+                nPn, oSG, oSC, oIDs, ojiT, overt, okeep = tracking.SeedInit(ids.copy(), sll.copy(), cand.copy(), latT, lonT, g["Yf"], g["Xf"],
+                                                                           g["resol"], tmask, xIceConc=sic0, iverbose=0)
+            assert nPn >= nP, nPn
+            cand_idx = np.asarray(okeep, dtype=np.int32)[:nP]
+            jiT0 = np.asarray(ojiT, dtype=np.int64)[:nP]
+            assert np.array_equal(np.asarray(oIDs)[:nP], ids[cand_idx])
+            yx0 = np.ascontiguousarray(cand[cand_idx])
+            fpar = dict(seed=77, umax=0.9, drift=0.3, ripple=0.1)
+            u, v, sic = syn.make_fields(g, K=K, **fpar)
+            sic[:, pol[0]:pol[1], pol[2]:pol[3]] = 0.03
+            mesh = np.array([Nj, Ni, 12.5, 1.0, -250., 150.])
+            fields = np.array([K, 77, 0.9, 0.3, 0.1])
+            extra = dict(island=np.array(isl), polynya=np.array(pol), seed_cancelled=np.int64(int(cand_idx[-1]) + 1 - nP),
+                         lat_sum=np.float64(latT.sum()), lon_sum=np.float64(lonT.sum()))
+            print("   %s: SeedInit kept %d of the first %d candidates (%d cancelled before the %d-th kept)"
+                  % (fname, nPn, ncand, int(extra["seed_cancelled"]), nP))
+        vert0 = vertices_of(jiT0)
+        rng = np.random.default_rng(1239)
+        wf = np.full(nP, kstrt, dtype=np.int64); wl = np.full(nP, kstrt + Nt - 1, dtype=np.int64)
+        late = rng.choice(nP, 12, replace=False); wf[late] = kstrt + rng.integers(1, 20, 12)
+        early = rng.choice(nP, 12, replace=False); wl[early] = kstrt + Nt - 1 - rng.integers(1, 20, 12)
+        all_f = np.full(nP, kstrt, dtype=np.int64); all_l = np.full(nP, 10**9, dtype=np.int64)
+        out = {}
+        for strat in (1, 0):
+            for tag, (rf, rl) in (("", (all_f, all_l)), ("w", (wf, wl))):
+                with quiet():
+                    pos, msk, jit_rec, alive_rec, vert, codes = reference_loop(g, tmask, u, v, sic, yx0, jiT0, vert0, rf, rl, kstrt, Nt, rdt, strat)
+                last = np.full((nP, 2), FILL)
+                for k in range(Nt + 1):
+                    m = msk[k] == 1
+                    last[m] = pos[k][m]
+                key = "s%d%s" % (strat, tag)
+                out["digest_" + key] = traj_digest(pos, msk, jit_rec, alive_rec)
+                out["last_pos_" + key] = last
+                out["jiT_end_" + key] = jit_rec[-1].astype(np.int32)
+                out["alive_end_" + key] = alive_rec[-1]
+                out["codes_" + key] = codes
+                print("   %s strat %d %-8s: %d particle-steps, crossings by code %s, dead %d/%d" %
+                      (fname, strat, "windows" if tag else "all", int(msk[1:].sum()), codes[1:].tolist(), int((alive_rec[-1] == 0).sum()), nP))
+        save(fname, kind=np.array(cfg), mesh=mesh, buoys=np.array([nAll, 1234, nP]), fields=fields,
+             probe_records=np.array(PROBE_RECORDS), u_sum=np.array([u[k].astype(np.float64).sum() for k in PROBE_RECORDS]),
+             v_sum=np.array([v[k].astype(np.float64).sum() for k in PROBE_RECORDS]), sic_sum=np.float64(sic.sum(dtype=np.float64)),
+             yx0_sum=np.float64(yx0.sum()), cand_idx=cand_idx,
+             jiT0=jiT0.astype(np.int32), rec_first=wf, rec_last=wl, kstrt=np.int64(kstrt), Nt=np.int64(Nt), rdt=np.float64(rdt), **extra, **out)
+        del g, u, v, sic
+
+
 # --------------------------------------------------------------------------- G7
 def h5_values(path, name, fmt):
     txt = subprocess.run(["/opt/conda/bin/h5dump", "-m", fmt, "-d", name, path], check=True,
@@ -719,7 +821,7 @@ def g10_nemoseed():
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, fn in (("g1", g1_inside), ("g2", g2_intersect), ("g3", g3_crossing), ("g4", g4_survive), ("g4b", g4b_survive_wide),
-                     ("g5", g5_seedinit), ("g5b", g5b_seedinit_on_points), ("g5c", g5c_seedinit_larger_mesh), ("g5d", g5d_nearest_point_local_box), ("g6", g6_trajectories), ("g6b", g6b_fast_flow_trajectories), ("g6cd", g6cd_baseline_cuts),
+                     ("g5", g5_seedinit), ("g5b", g5b_seedinit_on_points), ("g5c", g5c_seedinit_larger_mesh), ("g5d", g5d_nearest_point_local_box), ("g6", g6_trajectories), ("g6b", g6b_fast_flow_trajectories), ("g6cd", g6cd_baseline_cuts), ("g6ef", g6ef_curvilinear_cuts),
                      ("g7", g7_projection), ("g8", g8_timespan),
                      ("g9", g9_haversine), ("g10", g10_nemoseed)):
         if not only or name in only:

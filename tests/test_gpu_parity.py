@@ -194,7 +194,7 @@ def _cut_tracker(g):
     """one tracker per BASELINE mesh with the workload's 32 records resident (6.4 GB at 4096^2), shared by the G6c / G6d cases"""
     from conftest import baseline_cut_case
     grid, u, v, sic, yx0 = baseline_cut_case(g)
-    key = grid["Yf"].shape
+    key = grid["Yf"].shape + (str(g["kind"]) if "kind" in g else "regular",)
     if key not in _CUT_TRK:
         for t in _CUT_TRK.values():
             t.close()
@@ -206,7 +206,7 @@ def _cut_tracker(g):
     return _CUT_TRK[key], yx0, u.shape[0]
 
 
-@pytest.mark.parametrize("name", ["g6c_c2cut.npz", "g6d_c3cut.npz"])          # (outermost: varies slowest -- one tracker per mesh)
+@pytest.mark.parametrize("name", ["g6c_c2cut.npz", "g6d_c3cut.npz", "g6f_c5shape_cut.npz", "g6e_c3warp_cut.npz"])   # (outermost: one tracker per mesh)
 @pytest.mark.parametrize("mode", ["step", "step_w", "run", "run_unsorted", "run_w", "run_w_unsorted"])
 @pytest.mark.parametrize("strat", [1, 0])
 def test_g6cd_reference_trajectories_on_the_baseline_workloads(golden, name, mode, strat):
@@ -214,7 +214,8 @@ def test_g6cd_reference_trajectories_on_the_baseline_workloads(golden, name, mod
     C2 (512^2) and C3 (4096^2) workloads, 32 resident records cycled, both velocity rules -- record by record with per-record digests
     (`step`), through fused launches sorted / unsorted (`run`), and -- the case rounds 1-3 tied to the reference only transitively --
     FUSED LAUNCHES WITH PER-BUOY RECORD WINDOWS (`run_w`: 12 late starters, 12 early stoppers; the launches that cut through a
-    window run the windowed kernel form, the others the plain one), by the final state."""
+    window run the windowed kernel form, the others the plain one), by the final state.
+    G6e / G6f (round 4): the same on bench.py's curvilinear workloads (`--warp 1.0` C3; `--config c5shape` with its island and polynya)."""
     from conftest import traj_digest_row
     g = golden(name)
     trk, yx0, K = _cut_tracker(g)
@@ -246,6 +247,34 @@ def test_g6cd_reference_trajectories_on_the_baseline_workloads(golden, name, mod
     assert np.array_equal(st["vJIt"], g["jiT_end_" + key]) and np.array_equal(st["iAlive"], g["alive_end_" + key])
     assert np.array_equal(st["yx"], g["last_pos_" + key])
     assert int(g["codes_" + key].sum()) > 0.05 * Nt * len(yx0)
+
+
+def test_g6ef_the_products_own_seeding_gives_the_cuts_host_cells(golden):
+    """the buoys of G6e / G6f are seeded by the REFERENCE (FindContainingCell; SeedInit): the product's own seeding of the same
+    candidates -- what bench.py does at 1e7 -- keeps the same buoys in the same host cells"""
+    from conftest import baseline_cut_case
+    g = golden("g6e_c3warp_cut.npz")
+    trk, yx0, _ = _cut_tracker(g)
+    grid = baseline_cut_case(g)[0]
+    found, ji = trk.ctx.find_cells(yx0, syn.nearest_t_index(grid, yx0).astype(np.int32))
+    assert found.all() and np.array_equal(ji, g["jiT0"])
+    g = golden("g6f_c5shape_cut.npz")
+    trk, yx0, _ = _cut_tracker(g)
+    grid = baseline_cut_case(g)[0]
+    Nj, Ni = grid["Yf"].shape
+    nAll, bseed, nP = (int(x) for x in g["buoys"])
+    ncand = int(g["cand_idx"][-1]) + 1
+    rng = np.random.default_rng(bseed)
+    cand = np.stack([rng.uniform(grid["Yt"].min() + 30, grid["Yt"].max() - 30, nAll), rng.uniform(grid["Xt"].min() + 30, grid["Xt"].max() - 30, nAll)],
+                    axis=1)[:ncand].astype(np.float32).astype(np.float64)
+    ll = orc.CartNPSkm2Geo1D(np.stack([grid["Yt"].ravel(), grid["Xt"].ravel()], axis=1))
+    latT, lonT = np.ascontiguousarray(ll[:, 0].reshape(Nj, Ni)), np.ascontiguousarray(np.mod(ll[:, 1], 360.).reshape(Nj, Ni))
+    assert latT.sum() == float(g["lat_sum"]) and lonT.sum() == float(g["lon_sum"])
+    sll = orc.CartNPSkm2Geo1D(cand); sll[:, 1] = np.mod(sll[:, 1], 360.)
+    sic0 = np.ones((Nj, Ni)); j0, j1, i0, i1 = (int(x) for x in g["polynya"]); sic0[j0:j1, i0:i1] = 0.03
+    ji, keep, why = trk.ctx.seed_init(sll, cand, latT, lonT, grid["resol"], sic0)
+    k = np.where(keep == 1)[0]
+    assert np.array_equal(k, g["cand_idx"]) and np.array_equal(ji[k], g["jiT0"]) and ncand - len(k) == int(g["seed_cancelled"])
 
 
 def test_g6cd_release_the_shared_trackers():

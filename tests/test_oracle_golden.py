@@ -208,12 +208,15 @@ def test_g6b_fast_flow_trajectories_bit_exact(golden, strat):
     assert np.array_equal(tr.alive, g["alive_end_s%d" % strat]) and tr.ncross == int(g["codes_s%d" % strat].sum())
 
 
-@pytest.mark.parametrize("name", ["g6c_c2cut.npz", "g6d_c3cut.npz"])
+@pytest.mark.parametrize("name", ["g6c_c2cut.npz", "g6d_c3cut.npz", "g6f_c5shape_cut.npz", "g6e_c3warp_cut.npz"])
 def test_g6cd_reference_trajectories_on_the_baseline_workloads(golden, name):
     """G6c / G6d: the REFERENCE's trajectories on inputs cut from BASELINE configs 2 and 3 themselves -- the first 10^3 buoys x 100
     records of bench.py's C2 / C3 workloads (same grid, same seeds, the 32 resident records cycled) -- both velocity rules, with and
     without per-buoy record windows.  The oracle walks them bit for bit: per-record digests, final positions, cells, alive.
-    (The four variants advance in lockstep so that each record is promoted to fp64 once, into buffers that are reused.)"""
+    (The four variants advance in lockstep so that each record is promoted to fp64 once, into buffers that are reused.)
+    G6e / G6f (round 4): the same on bench.py's CURVILINEAR workloads -- C3 sheared and stretched (`--warp 1.0`; host cells from the
+    reference's FindContainingCell) and the NANUK4-shaped mesh of `--config c5shape` (seeds kept by the reference's SeedInit, an island,
+    a polynya in which 2 % of the cut's buoys die, flow up to 0.9 m/s)."""
     from conftest import baseline_cut_case, traj_digest_row
     g = golden(name)
     grid, u, v, sic, yx0 = baseline_cut_case(g)
@@ -226,9 +229,12 @@ def test_g6cd_reference_trajectories_on_the_baseline_workloads(golden, name):
                                                         nthreads=4, **kw), yx0.copy())
     bu, bv = np.empty(u.shape[1:]), np.empty(u.shape[1:])
     bs = np.ones(u.shape[1:])                                       # (siconc is 1 everywhere in the BASELINE fields: checked by the rebuild)
+    ice_varies = "kind" in g and str(g["kind"]) == "c5shape"        # ... but for the polynya of the C5-shape workload
     for jt in range(Nt):
         jrec = jt + kstrt
         np.copyto(bu, u[jrec % K]); np.copyto(bv, v[jrec % K])
+        if ice_varies:
+            np.copyto(bs, sic[jrec % K])
         for key, (tr, last) in runs.items():
             pn, mn = tr.step(jrec, bu, bv, bs)
             if key.endswith("w"):                                   # the driver pre-writes a late starter's seed position (:289-312)
@@ -240,6 +246,7 @@ def test_g6cd_reference_trajectories_on_the_baseline_workloads(golden, name):
         assert np.array_equal(last, g["last_pos_" + key]) and np.array_equal(tr.jiT, g["jiT_end_" + key]), key
         assert np.array_equal(tr.alive, g["alive_end_" + key]) and tr.ncross == int(g["codes_" + key].sum()), key
         assert tr.ncross > 0.05 * Nt * len(yx0)
+        assert (tr.alive == 0).sum() == (20 if ice_varies else 0)
 
 
 def test_g5d_nearest_point_with_a_previous_position(golden):
