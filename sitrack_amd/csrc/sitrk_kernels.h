@@ -16,7 +16,7 @@
 // The ablation hooks below give WRONG results by design (timing only, profiles/r03s_*): they exist in diagnostic builds
 // (`make DIAG=1`) and nowhere else -- a stray -D must not ship a wrong tracker that still exports every symbol.
 #if (defined(SITRK_ABL_NOEDGE) || defined(SITRK_ABL_NODIAG) || defined(SITRK_ABL_VEL2) || defined(SITRK_ABL_NOK9) || \
-     defined(SITRK_NO_LAZY_HIT)) && !defined(SITRK_DIAG)
+     defined(SITRK_ABL_VELCONST) || defined(SITRK_ABL_VELLDS) || defined(SITRK_NO_LAZY_HIT)) && !defined(SITRK_DIAG)
 #error "SITRK_ABL_* / SITRK_NO_LAZY_HIT are diagnostic ablations (wrong results): they need -DSITRK_DIAG (make DIAG=1)"
 #endif
 
@@ -932,7 +932,12 @@ static constexpr int kRunBlock = SITRK_RUN_BLOCK;
 #endif
 // In-kernel stamps (diagnostic builds, `make DIAG=1`, knob "stamps"): where ONE wave's time goes inside a record.  s_memtime ticks
 // are shader cycles; the values go to a buffer nothing else reads.  SITRK_STAMP(k) closes interval k.
-#ifdef SITRK_DIAG
+#if defined(SITRK_DIAG) && defined(SITRK_NO_STAMPS)      // ablation builds that must keep the shipped register budget
+#define SITRK_STAMP_DECL const bool st_on = false;
+#define SITRK_STAMP_START
+#define SITRK_STAMP(k)
+#define SITRK_STAMP_FLUSH(widx)
+#elif defined(SITRK_DIAG)
 #define SITRK_STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = 0; const bool st_on = ra.stamps != nullptr;
 #define SITRK_STAMP_START if (st_on) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t) :: "memory"); }
 #define SITRK_STAMP(k) if (st_on) { unsigned long long st_n; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_n) :: "memory"); st_acc[k] += st_n - st_t; st_t = st_n; }
@@ -1061,6 +1066,24 @@ __global__ __launch_bounds__(kRunBlock, WINDOW ? SITRK_RUN_WAVES_WINDOW : SITRK_
 #endif
 #if SITRK_PRIO_LOADS > 0
         __builtin_amdgcn_s_setprio(SITRK_PRIO_BASE);
+#endif
+#ifdef SITRK_ABL_VELCONST               // ablation (timing only, WRONG results): a uniform drift instead of the record's velocities, the
+        {                                   // loads kept as dependencies -- from global memory as shipped, or (SITRK_ABL_VELLDS) as LDS
+#ifdef SITRK_ABL_VELLDS                     // reads at a cell-dependent address: what staging u/v patches through LDS could buy at best
+            typedef __attribute__((address_space(3))) const float lds_cf;
+            const unsigned la_ = inl ? lo : geo_la;
+            const float l0 = *(lds_cf *)(uintptr_t)(la_ + kLdsBias), l1 = *(lds_cf *)(uintptr_t)(la_ + kLdsBias + 4),
+                        l2 = *(lds_cf *)(uintptr_t)(la_ + kLdsBias + 8), l3 = *(lds_cf *)(uintptr_t)(la_ + kLdsBias + 12);
+#else
+            const FT l0 = fu0, l1 = fu1, l2 = fv0, l3 = fv1;
+#endif
+            float cu0, cu1, cv0, cv1;       // 0.1 and 0.05 m/s, each "computed from" one loaded value
+            asm volatile("v_mov_b32 %0, 0x3dcccccd" : "=v"(cu0) : "v"(l0));
+            asm volatile("v_mov_b32 %0, 0x3dcccccd" : "=v"(cu1) : "v"(l1));
+            asm volatile("v_mov_b32 %0, 0x3d4ccccd" : "=v"(cv0) : "v"(l2));
+            asm volatile("v_mov_b32 %0, 0x3d4ccccd" : "=v"(cv1) : "v"(l3));
+            fu0 = (FT)cu0; fu1 = (FT)cu1; fv0 = (FT)cv0; fv1 = (FT)cv1;
+        }
 #endif
         double zU, zV;
         FT su = 0, sv = 0;                               // UVS == 1: the selected candidates as loaded
