@@ -1,6 +1,8 @@
 #!/bin/bash
 # GPU box: the fresh-records leg with 64 resident records (launches of 32 while the other 32 are committed on the ingest stream)
 # against the default (commits on the compute stream), per library variant.   tools/fresh_overlap_ab.sh <tag> "<variants>"
+# (the svlow / cuN variants of profiles/r04an_fresh_overlap_ab.txt created the ingest stream with hipStreamCreateWithPriority(lowest) /
+#  hipExtStreamCreateWithCUMask(N low bits) in sitrk_create: two-line hooks that were removed again after the measurement)
 TAG=$1; VARS=$2
 OUT=gpurun_out/${TAG}_fresh_overlap.txt; : > $OUT
 for v in $VARS; do for mode in "" "--fresh-overlap"; do
