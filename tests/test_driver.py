@@ -905,3 +905,44 @@ def test_hdf5_reader_on_netcdf4_like_layout(tmp_path):
         assert np.array_equal(r.var("u_ice", np.array([0, 5])), u[[0, 5]])            # fancy index: read all, then numpy
     nrec, vt = ncio.ModelFileTimeInfo(fn)[:2]
     assert nrec == 6 and np.array_equal(vt, tc.astype('i4'))
+
+
+@pytest.mark.parametrize("fmt", ["nc3", "h5"])
+def test_model_records_box_reads(tmp_path, fmt):
+    """`ModelRecords.fields_box_into` -- the hyperslab of the reference's whole-record reads (si3_part_tracker.py:372-374) that the
+    driver reads straight into the library's staging: equal to slicing the whole record, for both file layouts, into buffers of the
+    file's own precision and of double precision; values that do not survive the cast to a narrower buffer are refused."""
+    from sitrack_amd import h5lite
+    if fmt == "h5" and (not h5lite.available() or ncio.backend() == "netCDF4"):
+        pytest.skip("the libhdf5 path is not the one ncio takes here")
+    rng = np.random.default_rng(3)
+    nrec, Nj, Ni = 4, 23, 37
+    flds = {n: rng.standard_normal((nrec, Nj, Ni)).astype('f4') for n in ("u_ice", "v_ice", "siconc")}
+    wide = rng.standard_normal((nrec, Nj, Ni))                                   # float64 values with no float32 twin
+    tc = (850608000 + 1800 + 3600 * np.arange(nrec)).astype('f8')
+    fn = str(tmp_path / "TEST4-EXP01_1h_19961215_19961216_icemod.nc")
+    variables = {"time_counter": ('f8', ('time_counter',), tc, {"units": ncio.tunits_default})}
+    for n, a in flds.items():
+        variables[n] = ('f4', ('time_counter', 'y', 'x'), a, None)
+    variables["wide"] = ('f8', ('time_counter', 'y', 'x'), wide, None)
+    variables["narrowable"] = ('f8', ('time_counter', 'y', 'x'), flds["u_ice"].astype('f8'), None)
+    (_write_nc3 if fmt == "nc3" else _write_h5_like_nc3)(fn, {"time_counter": None, "y": Nj, "x": Ni}, variables)
+    rec = ncio.ModelRecords(fn)
+    try:
+        assert rec.time(2) == int(tc[2])
+        for (j0, j1, i0, i1) in ((0, Nj, 0, Ni), (5, 17, 8, 31), (22, 23, 36, 37), (3, 4, 0, Ni)):
+            for dt in ('f4', 'f8'):
+                outs = [np.full((j1 - j0, i1 - i0), np.nan, dtype=dt) for _ in range(3)]
+                rec.fields_box_into(2, j0, j1, i0, i1, outs)
+                for o, n in zip(outs, ("u_ice", "v_ice", "siconc")):
+                    assert np.array_equal(o, flds[n][2, j0:j1, i0:i1])
+        outs = [np.empty((6, Ni), dtype='f4') for _ in range(3)]
+        rec.fields_rows_into(1, 9, 15, outs)                                      # whole rows
+        assert all(np.array_equal(o, flds[n][1, 9:15]) for o, n in zip(outs, ("u_ice", "v_ice", "siconc")))
+        o4 = [np.empty((4, 5), dtype='f4')]
+        rec.fields_box_into(0, 1, 5, 2, 7, o4, names=("narrowable",))             # float64 file values that ARE float32 values
+        assert np.array_equal(o4[0], flds["u_ice"][0, 1:5, 2:7])
+        with pytest.raises(ValueError, match="not exactly representable"):
+            rec.fields_box_into(0, 1, 5, 2, 7, o4, names=("wide",))
+    finally:
+        rec.close()
