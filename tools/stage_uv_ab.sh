@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs profiles/r04ba_stage_uv_kernel.patch applied: the knob stage_uv is not in the shipped library -- DESIGN 3.2 item 39)
 # GPU box: the staged small-set form of the fused loop (knob stage_uv) against the plain one.   tools/stage_uv_ab.sh <tag>
 TAG=${1:-r04aw}; OUT=gpurun_out/${TAG}_stage_uv.txt; : > $OUT
 for r in 1 2 3; do for s in 0 1; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs profiles/r04ba_stage_uv_kernel.patch applied: the knob stage_uv is not in the shipped library -- DESIGN 3.2 item 39)
 # GPU box: the staged form with 64- / 128-thread workgroups (one / two waves behind each per-record barrier).  tools/stage_uv_block_ab.sh <tag>
 TAG=${1:-r04ax}; OUT=gpurun_out/${TAG}_stage_uv_block.txt; : > $OUT
 for r in 1 2; do for v in b64 b128; do for t in "stage_uv=0" "stage_uv=1" "stage_uv=0,patch_kb=8" "stage_uv=1,patch_kb=8" "stage_uv=1,patch_kb=4"; do
