@@ -143,7 +143,7 @@ def main():
             allt[config]["isa"] = json.load(open(isa_path))["kernels"].get("advect_step_kernel<float,1,false,512>")
         for k in ("valu_per_wave_fixed", "valu_per_wave_per_record", "valu_terms_source", "valu64_frac", "valu64_frac_source",
                   "salu_per_wave_fixed", "salu_per_wave_per_record", "valu_main_path_per_wave_record",
-                  "valu_crossing_path_per_wave_record", "valu_paths_source", "crossing_rate"):
+                  "valu_crossing_path_per_wave_record", "valu_paths_source", "crossing_rate", "valu64_frac_counters_lower_bound", "note"):
             if k in prev:                         # fitted by tools/fit_valu_terms.py from several launch lengths: keep
                 allt[config + "_fused" if fused else config][k] = prev[k]
         json.dump(allt, open(tj, "w"), indent=1)
